@@ -1,0 +1,151 @@
+/* vx_abi.h -- C-ABI of libvx.so: the MI355X (gfx950) native kernels of the VISTA sparse voxel
+ * backbone path (hard voxelization + mean VFE + SubMConv3d / SparseConv3d stack).
+ *
+ * Boundary rules:
+ *  - flat extern "C" functions, plain pointers and sizes, no C++ / torch types;
+ *  - every function returns int32 status: 0 = ok, < 0 = error (text: vx_last_error(), thread-local);
+ *  - the CALLER owns all memory. Pointers named d_* / documented "device" are device pointers of
+ *    the current HIP device; scratch comes in through an explicit workspace whose size the
+ *    matching *_workspace_bytes() query returns. No function here allocates device memory;
+ *  - every launch goes to the caller's stream (void* = hipStream_t, e.g.
+ *    torch.cuda.current_stream().cuda_stream) and is asynchronous, except where a function is
+ *    documented to return a host count (one small D2H copy + stream synchronize);
+ *  - re-entrant and thread-safe (no mutable globals besides the thread-local error text).
+ *
+ * What each entry point replaces in the reference is cited as file:line under /root/reference.
+ * The reference's FFI for the sparse part is the third-party `spconv` package (not vendored:
+ * README.md:19,44-53); those entries cite the reference's call sites instead.
+ */
+#ifndef VX_ABI_H_
+#define VX_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK 0
+#define VX_ERR_ARG (-1)     /* bad argument (null pointer, shape/limit violated) */
+#define VX_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define VX_ERR_WORKSPACE (-3) /* workspace too small */
+#define VX_ERR_CAPACITY (-4)  /* an output capacity was exceeded */
+
+#define VX_F32 0
+#define VX_BF16 1
+
+/* epilogue flags of vx_spconv_fwd */
+#define VX_EPI_RELU 1
+
+int32_t vx_version(void);
+const char* vx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hard voxelization + mean VFE.
+ * Replaces: det3d/ops/point_cloud/point_cloud_ops.py:138-221 (points_to_voxel_new) /:224-296,
+ *           det3d/core/input/voxel_generator.py:21-39 (VoxelGenerator.generate),
+ *           det3d/models/readers/voxel_encoder.py:206-211 (mean VFE, fused),
+ *           det3d/torchie/parallel/collate.py:135-142 (batch-index column of coordinates).
+ *
+ * d_points     device f32[n_points][n_feat] (xyz first)
+ * voxel_size   HOST f32[3] (x,y,z), range HOST f32[6] (xmin,ymin,zmin,xmax,ymax,zmax), already fp32
+ * batch_idx    value written to column 0 of d_coords
+ * d_coords     device int32[cap][4]  (batch, z, y, x), voxel id = order of first point
+ * d_num_points device int32[cap]     min(count, max_points)
+ * d_voxels     device f32[cap][max_points][n_feat] or NULL (rows [0,M) fully written, zero padded)
+ * d_mean       device f32[cap][n_feat] or NULL (sum of the kept points / num_points)
+ * cap          row capacity of the outputs; M <= min(n_points, max_voxels) always holds
+ * d_num_voxels device int64[1]: M
+ * h_num_voxels HOST int64[1] or NULL; when non-NULL the call synchronises the stream and stores M
+ * ------------------------------------------------------------------------------------------- */
+size_t vx_voxelize_workspace_bytes(int64_t n_points);
+int32_t vx_voxelize_hard(const float* d_points, int64_t n_points, int32_t n_feat,
+                         const float* voxel_size, const float* range, int32_t max_points,
+                         int64_t max_voxels, int32_t batch_idx, int32_t* d_coords,
+                         int32_t* d_num_points, float* d_voxels, float* d_mean, int64_t cap,
+                         int64_t* d_num_voxels, int64_t* h_num_voxels, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rulebooks (indice pairs). Stored output-major: nbr[k][o] = input row feeding output row o
+ * through kernel offset k = (kz*KH + ky)*KW + kx, or -1. Row stride of nbr is nbr_ld (>= n_out).
+ * Replaces spconv's indice-pair generation behind
+ *   det3d/models/backbones/scn.py:28-38,333 (SubMConv3d, cached under indice_key) and
+ *   det3d/models/backbones/scn.py:338-361, multiview.py:39-82 (SparseConv3d).
+ * d_coords device int32[n][4] (batch,z,y,x); shape HOST int32[3] (D,H,W); ksize/stride/pad HOST int32[3].
+ * ------------------------------------------------------------------------------------------- */
+size_t vx_rulebook_workspace_bytes(int64_t n_in, int32_t batch, const int32_t* out_shape);
+
+/* submanifold: outputs == inputs (same rows); padding is ksize/2 */
+int32_t vx_rulebook_subm(const int32_t* d_coords, int64_t n, int32_t batch, const int32_t* shape,
+                         const int32_t* ksize, int32_t* d_nbr, int64_t nbr_ld, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* strided conv, phase 1: find the active output set. Leaves its state in the workspace, returns
+ * the number of output sites in *h_n_out (synchronises the stream). out_shape is written (HOST). */
+int32_t vx_rulebook_conv_count(const int32_t* d_coords, int64_t n_in, int32_t batch,
+                               const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
+                               const int32_t* pad, int32_t* out_shape, int64_t* h_n_out,
+                               void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* strided conv, phase 2 (same workspace, untouched since phase 1): output coordinates sorted by
+ * linear index ((b*D+z)*H+y)*W+x, the neighbour table, and optionally its transpose
+ * d_nbr_t[k][i] = output row fed by input row i through offset k, or -1 (row stride nbr_t_ld). */
+int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, int32_t batch,
+                              const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
+                              const int32_t* pad, int64_t n_out, int32_t* d_out_coords,
+                              int32_t* d_nbr, int64_t nbr_ld, int32_t* d_nbr_t, int64_t nbr_t_ld,
+                              void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* pair-list view (spconv's indice_pairs): d_pairs int32[K][2][n_out] ((in,out) per offset, ordered
+ * by output row, -1 padded), d_pair_num int32[K]. Wavefront-ballot compaction. */
+size_t vx_pairs_workspace_bytes(int32_t kvol, int64_t n_out);
+int32_t vx_nbr_to_pairs(const int32_t* d_nbr, int64_t nbr_ld, int32_t kvol, int64_t n_out,
+                        int32_t* d_pairs, int32_t* d_pair_num, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sparse convolution, forward (implicit GEMM, output-stationary, MFMA):
+ *   out[o] = epi( sum_k W[:,k,:] . in[nbr[k][o]] + bias )
+ *   epi(x) = relu?( x * scale + shift + residual[o] )     (scale/shift/residual optional)
+ * Replaces spconv's conv forward behind SubMConv3d / SparseConv3d (call sites above) and, through
+ * the optional epilogue, the BatchNorm1d(eval) + ReLU + residual add of scn.py:82-98.
+ * d_in   device [n_in][cin], d_out device [n_out][cout], d_residual device [n_out][cout] or NULL
+ * d_weight device [cout][kvol][cin] (KRSC, the nn.Parameter layout), dtype = VX_F32 | VX_BF16 for
+ * in/out/weight/residual; bias/scale/shift are always f32[cout] (or NULL).
+ * ------------------------------------------------------------------------------------------- */
+int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
+                      int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
+                      int64_t n_out, const float* d_bias, const float* d_scale,
+                      const float* d_shift, const void* d_residual, int32_t flags, void* d_out,
+                      int32_t dtype, void* stream);
+
+/* dgrad: din[i] = sum_k W[:,k,:]^T . dout[nbr_t[k][i]]  (input-stationary, atomic-free).
+ * For a submanifold conv pass the forward table with subm=1 (nbr_t[k] == nbr[kvol-1-k]). */
+int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t cout, const void* d_weight,
+                        int32_t kvol, int32_t cin, const int32_t* d_nbr_t, int64_t nbr_t_ld,
+                        int64_t n_in, int32_t subm, void* d_din, int32_t dtype, void* stream);
+
+/* wgrad: dW[co][k][ci] = sum over the pairs (i,o) of offset k of dout[o][co] * in[i][ci], from the
+ * compacted pair lists of vx_nbr_to_pairs (exact FLOPs); two-pass slab reduction, atomic-free and
+ * bitwise reproducible. d_dw f32[cout][kvol][cin]. Replaces spconv's weight gradient reached
+ * through autograd at det3d/core/utils/dist_utils.py:50-56 (loss.backward()). */
+size_t vx_spconv_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t kvol, int64_t n_out);
+int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, const void* d_dout,
+                        int64_t n_out, int32_t cout, const int32_t* d_pairs,
+                        const int32_t* d_pair_num, int32_t kvol, float* d_dw, int32_t dtype,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SparseConvTensor.dense(): zero-filled [batch][c][D][H][W] with out[b][:,z,y,x] = feat[row].
+ * Replaces spconv's dense() at det3d/models/backbones/scn.py:375, multiview.py:97,102.
+ * ------------------------------------------------------------------------------------------- */
+int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int32_t c,
+                    int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VX_ABI_H_ */

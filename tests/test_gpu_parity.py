@@ -1,0 +1,258 @@
+"""GPU parity tests proper: every call goes through the C-ABI (libvx.so via ctypes) and is checked
+against the CPU oracle (oracle/) and the committed golden vectors (tests/golden/)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+MAN = json.load(open(os.path.join(G, "voxel_manifest.json")))
+FULL = [k for k in MAN if not k.startswith("_") and os.path.exists(os.path.join(G, f"voxel_{k}.npz"))]
+BIG = [k for k in MAN if not k.startswith("_") and os.path.exists(os.path.join(G, f"voxel_{k}_sample.npz"))]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------- voxelization
+@pytest.mark.parametrize("name", FULL)
+def test_voxelize_golden_full(name, dev):
+    from vista_amd import ops
+    m = MAN[name]
+    d = np.load(os.path.join(G, f"voxel_{name}.npz"))
+    pts = torch.from_numpy(d["points"]).to(dev)
+    r = ops.voxelize(pts, m["voxel_size"], m["range"], m["max_points"], m["max_voxels"], batch_idx=3,
+                     with_voxels=True, with_mean=True)
+    assert r["num_voxels"] == d["coords"].shape[0]
+    c = r["coords"].cpu().numpy()
+    np.testing.assert_array_equal(c[:, 1:], d["coords"])            # bit-exact coordinates, reference order
+    assert np.all(c[:, 0] == 3)
+    np.testing.assert_array_equal(r["num_points"].cpu().numpy(), d["num_points"])
+    np.testing.assert_array_equal(r["voxels"].cpu().numpy(), d["voxels"])
+    if c.shape[0]:
+        # fp32 sums of <= T values: tolerance only covers summation order (voxel_encoder.py:206-211)
+        np.testing.assert_allclose(r["mean"].cpu().numpy(), d["mean"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_voxelize_golden_big(name, dev):
+    from vista_amd import ops
+    from vista_amd.synth import lidar_cloud
+    m = MAN[name]
+    pts_np = lidar_cloud(seed=m["seed"], sweeps=m["sweeps"])
+    assert sha(pts_np) == MAN["_points_sha256"][f"seed{m['seed']}_sweeps{m['sweeps']}"]
+    r = ops.voxelize(torch.from_numpy(pts_np).to(dev), m["voxel_size"], m["range"], m["max_points"],
+                     m["max_voxels"], with_voxels=True, with_mean=True)
+    assert r["num_voxels"] == m["M"]
+    assert sha(r["coords"][:, 1:].contiguous().cpu().numpy()) == m["coords_sha256"]
+    assert sha(r["num_points"].cpu().numpy()) == m["num_points_sha256"]
+    assert sha(r["voxels"].cpu().numpy()) == m["voxels_sha256"]
+
+
+def test_voxelize_vs_oracle_random_and_determinism(dev):
+    from oracle import voxelize_np as ov
+    from vista_amd import ops
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-3, 3, (50000, 5)).astype(np.float32)
+    vs, rg = [0.25, 0.25, 0.5], [-2.0, -2.0, -1.0, 2.0, 2.0, 1.0]
+    v, c, n = ov.voxelize(pts, vs, rg, 4, 100000)
+    t = torch.from_numpy(pts).to(dev)
+    r1 = ops.voxelize(t, vs, rg, 4, 100000, with_voxels=True)
+    r2 = ops.voxelize(t, vs, rg, 4, 100000, with_voxels=True)
+    np.testing.assert_array_equal(r1["coords"][:, 1:].cpu().numpy(), c)
+    np.testing.assert_array_equal(r1["num_points"].cpu().numpy(), n)
+    np.testing.assert_array_equal(r1["voxels"].cpu().numpy(), v)
+    np.testing.assert_allclose(r1["mean"].cpu().numpy(), ov.mean_vfe(v, n), rtol=1e-6, atol=1e-6)
+    for k in ("coords", "num_points", "voxels", "mean"):
+        assert torch.equal(r1[k], r2[k])  # run-to-run bitwise identical
+
+
+def test_voxel_generator_api(dev):
+    from vista_amd.voxel import VoxelGenerator, Voxelization, collate_voxels
+    d = np.load(os.path.join(G, "voxel_tiny_1sweep.npz"))
+    m = MAN["tiny_1sweep"]
+    gen = VoxelGenerator(m["voxel_size"], m["range"], m["max_points"], max_voxels=m["max_voxels"])
+    assert gen.grid_size.dtype == np.int64 and list(gen.grid_size) == m["grid_size"]
+    v, c, n = gen.generate(torch.from_numpy(d["points"]).to(dev))
+    np.testing.assert_array_equal(c.cpu().numpy(), d["coords"])
+    stage = Voxelization(cfg=dict(range=m["range"], voxel_size=m["voxel_size"],
+                                  max_points_in_voxel=m["max_points"], max_voxel_num=m["max_voxels"]))
+    res, _ = stage(dict(lidar=dict(points=torch.from_numpy(d["points"]).to(dev)), mode="val"), None)
+    vd = res["lidar"]["voxels"]
+    assert set(vd) == {"voxels", "coordinates", "num_points", "num_voxels", "shape"}
+    b = collate_voxels([vd, vd])
+    cc = b["coordinates"].cpu().numpy()
+    assert cc.shape == (2 * d["coords"].shape[0], 4)
+    np.testing.assert_array_equal(cc[d["coords"].shape[0]:, 0], 1)
+    np.testing.assert_array_equal(cc[:d["coords"].shape[0], 1:], d["coords"])
+
+
+# ---------------------------------------------------------------------------- rulebooks
+def random_sites(rng, batch, shape, n):
+    vol = int(np.prod(shape))
+    rows = []
+    for b in range(batch):
+        lin = rng.choice(vol, size=min(n, vol), replace=False)
+        z, r = np.divmod(lin, shape[1] * shape[2])
+        y, x = np.divmod(r, shape[2])
+        rows.append(np.stack([np.full_like(z, b), z, y, x], 1))
+    c = np.concatenate(rows).astype(np.int32)
+    return c[rng.permutation(c.shape[0])]
+
+
+GEOMS = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+         ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((1, 1, 3), (1, 1, 2), (0, 0, 1))]
+
+
+@pytest.mark.parametrize("ks,st,pd", GEOMS)
+def test_rulebook_conv_bit_exact(ks, st, pd, dev):
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(0)
+    shape = [21, 64, 72]
+    coords = random_sites(rng, 3, shape, 5000)
+    oc, nbr, osh = so.rulebook_conv(coords, shape, ks, st, pd)
+    rb = ops.rulebook_conv(torch.from_numpy(coords).to(dev), 3, shape, ks, st, pd, transpose=True)
+    assert rb.out_shape == osh and rb.n_out == oc.shape[0]
+    np.testing.assert_array_equal(rb.out_indices.cpu().numpy(), oc)
+    np.testing.assert_array_equal(rb.nbr.cpu().numpy(), nbr)
+    # pair-list view, bit-exact against the oracle's
+    pairs, num = so.nbr_to_pairs(nbr)
+    gp, gn = rb.pairs()
+    np.testing.assert_array_equal(gn.cpu().numpy(), num)
+    np.testing.assert_array_equal(gp.cpu().numpy(), pairs)
+    # transpose table
+    nt = rb.nbr_t.cpu().numpy()
+    kk, oo = np.nonzero(nbr >= 0)
+    ref_t = np.full_like(nt, -1)
+    ref_t[kk, nbr[kk, oo]] = oo
+    np.testing.assert_array_equal(nt, ref_t)
+
+
+def test_rulebook_subm_bit_exact(dev):
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(1)
+    shape = [11, 50, 60]
+    coords = random_sites(rng, 2, shape, 6000)
+    nbr = so.rulebook_subm(coords, shape, 3)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    np.testing.assert_array_equal(rb.nbr.cpu().numpy(), nbr)
+    pairs, num = so.nbr_to_pairs(nbr)
+    gp, gn = rb.pairs()
+    np.testing.assert_array_equal(gn.cpu().numpy(), num)
+    np.testing.assert_array_equal(gp.cpu().numpy(), pairs)
+
+
+def test_rulebook_empty(dev):
+    from vista_amd import ops
+    e = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    rb = ops.rulebook_conv(e, 1, [5, 6, 7], 3, 2, 1)
+    assert rb.n_out == 0 and rb.nbr.shape == (27, 0)
+    rb = ops.rulebook_subm(e, 1, [5, 6, 7], 3)
+    assert rb.nbr.shape == (27, 0)
+
+
+# ---------------------------------------------------------------------------- convolution
+CH = [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 32), (7, 9)]
+
+
+@pytest.mark.parametrize("cin,cout", CH)
+def test_conv_fwd_subm_vs_oracle(cin, cout, dev):
+    """fp32 tolerance: 1e-4 relative (north_star); observed error is summation-order only."""
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape = [9, 40, 40]
+    coords = random_sites(rng, 2, shape, 1500)
+    n = coords.shape[0]
+    feat = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    nbr = so.rulebook_subm(coords, shape, 3)
+    ref = so.conv_fwd(feat, w, nbr, bias)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    got = ops.conv_fwd(torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev), rb,
+                       bias=torch.from_numpy(bias).to(dev)).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-4 * scale, np.abs(got - ref).max() / scale
+
+
+@pytest.mark.parametrize("ks,st,pd", GEOMS)
+def test_conv_fwd_strided_and_epilogue(ks, st, pd, dev):
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(3)
+    shape = [11, 30, 34]
+    cin, cout = 32, 64
+    coords = random_sites(rng, 2, shape, 2500)
+    feat = rng.normal(size=(coords.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, *ks, cin)) / np.sqrt(np.prod(ks) * cin)).astype(np.float32)
+    oc, nbr, osh = so.rulebook_conv(coords, shape, ks, st, pd)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(oc.shape[0], cout)).astype(np.float32)
+    ref = np.maximum(so.conv_fwd(feat, w, nbr, None) * sc + sh + res, 0)
+    rb = ops.rulebook_conv(torch.from_numpy(coords).to(dev), 2, shape, ks, st, pd)
+    got = ops.conv_fwd(torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev), rb,
+                       scale=torch.from_numpy(sc).to(dev), shift=torch.from_numpy(sh).to(dev),
+                       residual=torch.from_numpy(res).to(dev), relu=True).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("subm", [True, False])
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 32), (64, 64), (128, 128), (128, 32)])
+def test_conv_grads_vs_oracle(subm, cin, cout, dev):
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(11)
+    shape = [9, 36, 36]
+    coords = random_sites(rng, 2, shape, 3000)
+    feat = rng.normal(size=(coords.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        nbr = so.rulebook_subm(coords, shape, 3)
+        rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    else:
+        oc, nbr, osh = so.rulebook_conv(coords, shape, 3, 2, 1)
+        rb = ops.rulebook_conv(torch.from_numpy(coords).to(dev), 2, shape, 3, 2, 1, transpose=True)
+    dout = rng.normal(size=(nbr.shape[1], cout)).astype(np.float32)
+    din_ref = so.conv_dgrad(dout, w, nbr, coords.shape[0])
+    dw_ref = so.conv_wgrad(feat, dout, nbr, w.shape)
+    din = ops.conv_dgrad(torch.from_numpy(dout).to(dev), torch.from_numpy(w).to(dev), rb).cpu().numpy()
+    dw = ops.conv_wgrad(torch.from_numpy(feat).to(dev), torch.from_numpy(dout).to(dev), rb, w.shape).cpu().numpy()
+    assert np.abs(din - din_ref).max() <= 1e-4 * np.abs(din_ref).max()
+    assert np.abs(dw - dw_ref).max() <= 1e-4 * np.abs(dw_ref).max()
+
+
+def test_to_dense(dev):
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(4)
+    shape = [2, 45, 50]
+    coords = random_sites(rng, 3, shape, 700)
+    lin = ((coords[:, 0].astype(np.int64) * 2 + coords[:, 1]) * 45 + coords[:, 2]) * 50 + coords[:, 3]
+    coords = coords[np.argsort(lin)]
+    feat = rng.normal(size=(coords.shape[0], 128)).astype(np.float32)
+    ref = so.to_dense(feat, coords, 3, shape)
+    got = ops.to_dense(torch.from_numpy(feat).to(dev), torch.from_numpy(coords).to(dev), 3, shape).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_ops_reject_cpu_tensors():
+    from vista_amd import ops
+    from vista_amd._lib import VxError
+    with pytest.raises(VxError):
+        ops.voxelize(torch.zeros(4, 5), [1, 1, 1], [0, 0, 0, 1, 1, 1], 3, 10)

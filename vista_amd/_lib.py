@@ -1,0 +1,86 @@
+"""ctypes binding of libvx.so (the C-ABI declared in include/vx_abi.h).
+
+There is no CPU fallback: if the library is missing the import of any op fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvx.so")
+
+c_void_p, c_int32, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+VX_F32, VX_BF16 = 0, 1
+VX_EPI_RELU = 1
+
+# name -> (restype, argtypes); mirrors include/vx_abi.h one to one
+SIGNATURES = {
+    "vx_version": (c_int32, []),
+    "vx_last_error": (ctypes.c_char_p, []),
+    "vx_voxelize_workspace_bytes": (c_size_t, [c_int64]),
+    "vx_voxelize_hard": (c_int32, [c_void_p, c_int64, c_int32, c_f32p, c_f32p, c_int32, c_int64, c_int32,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_i64p,
+                                   c_void_p, c_size_t, c_void_p]),
+    "vx_rulebook_workspace_bytes": (c_size_t, [c_int64, c_int32, c_i32p]),
+    "vx_rulebook_subm": (c_int32, [c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_void_p, c_int64,
+                                   c_void_p, c_size_t, c_void_p]),
+    "vx_rulebook_conv_count": (c_int32, [c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_i32p, c_i32p,
+                                         c_i32p, c_i64p, c_void_p, c_size_t, c_void_p]),
+    "vx_rulebook_conv_emit": (c_int32, [c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_i32p, c_i32p,
+                                        c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                        c_void_p, c_size_t, c_void_p]),
+    "vx_pairs_workspace_bytes": (c_size_t, [c_int32, c_int64]),
+    "vx_nbr_to_pairs": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "vx_spconv_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                c_void_p, c_int32, c_void_p]),
+    "vx_spconv_dgrad": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                  c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
+    "vx_spconv_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),
+    "vx_spconv_wgrad": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
+                                  c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "vx_to_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
+                              c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+class VxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvx.so once. Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VxError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vista_amd/csrc`. There is no CPU fallback for this path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vx_last_error()
+        raise VxError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def i32x3(v):
+    if isinstance(v, int):
+        v = [v, v, v]
+    v = [int(x) for x in v]
+    if len(v) != 3:
+        raise ValueError(f"expected an int or 3 ints, got {v}")
+    return (ctypes.c_int32 * 3)(*v)

@@ -1,0 +1,49 @@
+// SparseConvTensor.dense(): zero-fill [B][C][D][H][W] then scatter rows (HBM-bound).
+// Rows arrive sorted by linear index, so for a fixed channel consecutive rows land on consecutive
+// addresses: 64 rows are transposed through LDS and every wave-instruction writes one channel of
+// 64 rows (coalesced wherever the rows are x-adjacent).
+#include "vx_common.h"
+
+namespace {
+constexpr int kThreads = 256;
+constexpr int kRows = 64;
+
+__global__ __launch_bounds__(kThreads) void to_dense_f32(const float* __restrict__ feat,
+                                                         const int* __restrict__ coords,
+                                                         long long n, int c, int d, int hh, int ww,
+                                                         float* __restrict__ dense) {
+  extern __shared__ float tile[];  // [kRows][c + 1]
+  const int cp = c + 1;
+  const long long row0 = (long long)blockIdx.x * kRows;
+  const int rows = (int)((n - row0) < kRows ? (n - row0) : kRows);
+  for (int idx = threadIdx.x; idx < rows * c; idx += kThreads) {
+    const int rr = idx / c, cc = idx - rr * c;
+    tile[rr * cp + cc] = feat[(row0 + rr) * c + cc];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane >= rows) return;
+  const int4 q = *reinterpret_cast<const int4*>(coords + 4 * (row0 + lane));
+  const long long vol = (long long)d * hh * ww;
+  const long long sp = ((long long)q.y * hh + q.z) * ww + q.w;
+  float* dst = dense + (long long)q.x * c * vol + sp;
+  for (int cc = wave; cc < c; cc += kThreads / 64) dst[(long long)cc * vol] = tile[lane * cp + cc];
+}
+}  // namespace
+
+extern "C" int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int32_t c,
+                               int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(dtype == VX_F32, "to_dense: only VX_F32 is built in this revision");
+  VX_REQUIRE(shape && d_dense && batch >= 1 && c >= 1 && c <= 4096 && n >= 0, "to_dense: bad arguments");
+  const size_t total = (size_t)batch * c * shape[0] * shape[1] * shape[2];
+  VX_HIP(hipMemsetAsync(d_dense, 0, total * sizeof(float), stream));
+  if (n == 0) return VX_OK;
+  VX_REQUIRE(d_feat && d_coords, "to_dense: null pointer");
+  const size_t lds = (size_t)kRows * (c + 1) * sizeof(float);
+  to_dense_f32<<<(unsigned)vx_cdiv(n, kRows), kThreads, lds, stream>>>(
+      (const float*)d_feat, d_coords, n, c, shape[0], shape[1], shape[2], (float*)d_dense);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}

@@ -1,0 +1,376 @@
+// Rulebook (indice pair) generation on gfx950: lock-free open-addressing hash in HBM for
+// coordinate -> row lookups, an occupancy bitmap + popcount scan for the sorted, de-duplicated
+// output set of strided convolutions, wavefront-ballot compaction for the pair-list view.
+//
+// Semantics (spconv call sites det3d/models/backbones/scn.py:333-361,
+// multiview.py:33-86): conv (k, s, p, dilation 1), O = (I + 2p - k)/s + 1; input site i feeds
+// output o = (i + p - k')/s for every kernel offset k' with (i + p - k') % s == 0, 0 <= o < O.
+// Canonical order: outputs sorted by linear index ((b*D+z)*H+y)*W+x; offsets row-major.
+// The table is output-major: nbr[k][o] = input row or -1 (all phases are HBM/latency bound
+// integer work: coalesced over o, 16-byte hash probes, no GEMM shape anywhere).
+#include "vx_common.h"
+
+namespace {
+constexpr int kThreads = 256;
+
+struct ConvGeom {
+  int in_shape[3];
+  int out_shape[3];
+  int k[3], s[3], p[3];
+  int kvol;
+};
+
+__device__ __forceinline__ long long lin_idx(int b, int z, int y, int x, const int* sh) {
+  return (((long long)b * sh[0] + z) * sh[1] + y) * sh[2] + x;
+}
+
+__global__ __launch_bounds__(kThreads) void hash_clear(VxSlot* t, long long cap) {
+  long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i < cap) *reinterpret_cast<int4*>(&t[i]) = make_int4(-1, -1, -1, 0);
+}
+
+__global__ __launch_bounds__(kThreads) void hash_build(const int* __restrict__ coords, long long n,
+                                                       ConvGeom g, VxSlot* t, long long mask) {
+  long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  long long s = vx_hash_insert(t, mask, lin_idx(c.x, c.y, c.z, c.w, g.in_shape));
+  t[s].a = (int)i;  // duplicate coordinates (invalid input) keep one of their rows
+}
+
+// submanifold: one thread per (k, o), o fastest -> coalesced coordinate reads and table writes
+__global__ __launch_bounds__(kThreads) void subm_nbr(const int* __restrict__ coords, long long n,
+                                                     ConvGeom g, const VxSlot* __restrict__ t,
+                                                     long long mask, int* __restrict__ nbr,
+                                                     long long ld) {
+  const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int k = blockIdx.y;
+  if (o >= n) return;
+  const int kx = k % g.k[2], ky = (k / g.k[2]) % g.k[1], kz = k / (g.k[2] * g.k[1]);
+  const int4 c = *reinterpret_cast<const int4*>(coords + 4 * o);
+  const int z = c.y + kz - g.k[0] / 2, y = c.z + ky - g.k[1] / 2, x = c.w + kx - g.k[2] / 2;
+  int r = -1;
+  if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2])
+    r = vx_hash_find(t, mask, lin_idx(c.x, z, y, x, g.in_shape));
+  nbr[(long long)k * ld + o] = r;
+}
+
+// strided conv phase 1: every input marks the outputs it feeds in the occupancy bitmap
+__global__ __launch_bounds__(kThreads) void conv_mark(const int* __restrict__ coords, long long n,
+                                                      ConvGeom g, unsigned* __restrict__ bitmap) {
+  long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  for (int kz = 0; kz < g.k[0]; ++kz) {
+    const int tz = c.y + g.p[0] - kz;
+    if (tz < 0 || tz % g.s[0]) continue;
+    const int oz = tz / g.s[0];
+    if (oz >= g.out_shape[0]) continue;
+    for (int ky = 0; ky < g.k[1]; ++ky) {
+      const int ty = c.z + g.p[1] - ky;
+      if (ty < 0 || ty % g.s[1]) continue;
+      const int oy = ty / g.s[1];
+      if (oy >= g.out_shape[1]) continue;
+      for (int kx = 0; kx < g.k[2]; ++kx) {
+        const int tx = c.w + g.p[2] - kx;
+        if (tx < 0 || tx % g.s[2]) continue;
+        const int ox = tx / g.s[2];
+        if (ox >= g.out_shape[2]) continue;
+        const long long key = lin_idx(c.x, oz, oy, ox, g.out_shape);
+        atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bitmap_popc(const unsigned* __restrict__ bitmap,
+                                                        long long nwords, int* __restrict__ cnt) {
+  long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i < nwords) cnt[i] = __popc(bitmap[i]);
+}
+
+// phase 2: rank of a set bit = its row; rows come out sorted by linear index
+__global__ __launch_bounds__(kThreads) void conv_emit_coords(const unsigned* __restrict__ bitmap,
+                                                             const int* __restrict__ base,
+                                                             long long nwords, ConvGeom g,
+                                                             int* __restrict__ out_coords) {
+  long long w = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned bits = bitmap[w];
+  int row = base[w];
+  while (bits) {
+    const int b = __ffs(bits) - 1;
+    bits &= bits - 1;
+    long long key = (w << 5) + b;
+    const int x = (int)(key % g.out_shape[2]); key /= g.out_shape[2];
+    const int y = (int)(key % g.out_shape[1]); key /= g.out_shape[1];
+    const int z = (int)(key % g.out_shape[0]); key /= g.out_shape[0];
+    *reinterpret_cast<int4*>(out_coords + 4ll * row) = make_int4((int)key, z, y, x);
+    ++row;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void conv_nbr(const int* __restrict__ out_coords,
+                                                     long long n_out, ConvGeom g,
+                                                     const VxSlot* __restrict__ t, long long mask,
+                                                     int* __restrict__ nbr, long long ld,
+                                                     int* __restrict__ nbr_t, long long ld_t) {
+  const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int k = blockIdx.y;
+  if (o >= n_out) return;
+  const int kx = k % g.k[2], ky = (k / g.k[2]) % g.k[1], kz = k / (g.k[2] * g.k[1]);
+  const int4 c = *reinterpret_cast<const int4*>(out_coords + 4 * o);
+  const int z = c.y * g.s[0] - g.p[0] + kz, y = c.z * g.s[1] - g.p[1] + ky,
+            x = c.w * g.s[2] - g.p[2] + kx;
+  int r = -1;
+  if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2])
+    r = vx_hash_find(t, mask, lin_idx(c.x, z, y, x, g.in_shape));
+  nbr[(long long)k * ld + o] = r;
+  if (nbr_t && r >= 0) nbr_t[(long long)k * ld_t + r] = (int)o;
+}
+
+// ---- pair-list view: wavefront-ballot compaction ------------------------------------------------
+__global__ __launch_bounds__(kThreads) void pairs_count(const int* __restrict__ nbr, long long ld,
+                                                        long long n_out, long long nw,
+                                                        int* __restrict__ wcnt) {
+  const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int k = blockIdx.y;
+  const bool valid = o < n_out && nbr[(long long)k * ld + o] >= 0;
+  const unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && (o >> 6) < nw) wcnt[(long long)k * nw + (o >> 6)] = __popcll(m);
+}
+
+__global__ __launch_bounds__(kThreads) void pairs_write(const int* __restrict__ nbr, long long ld,
+                                                        long long n_out, long long nw,
+                                                        const int* __restrict__ woff,
+                                                        int* __restrict__ pairs) {
+  const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int k = blockIdx.y;
+  const int i = o < n_out ? nbr[(long long)k * ld + o] : -1;
+  const unsigned long long m = __ballot(i >= 0);
+  if (i < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int pos = woff[(long long)k * nw + (o >> 6)] - woff[(long long)k * nw] +
+                  __popcll(m & ((1ull << lane) - 1ull));
+  int* pin = pairs + (long long)k * 2 * n_out;
+  pin[pos] = i;
+  pin[n_out + pos] = (int)o;
+}
+
+__global__ void pairs_num(const int* __restrict__ woff, const int* __restrict__ wcnt, long long nw,
+                          int kvol, int* __restrict__ pair_num) {
+  const int k = threadIdx.x;
+  if (k >= kvol) return;
+  const long long last = (long long)(k + 1) * nw - 1;
+  pair_num[k] = woff[last] + wcnt[last] - woff[(long long)k * nw];
+}
+
+int fill_geom(ConvGeom* g, const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
+              const int32_t* pad, bool subm) {
+  g->kvol = 1;
+  for (int d = 0; d < 3; ++d) {
+    g->in_shape[d] = in_shape[d];
+    g->k[d] = ksize[d];
+    g->s[d] = subm ? 1 : stride[d];
+    g->p[d] = subm ? ksize[d] / 2 : pad[d];
+    if (in_shape[d] < 1 || g->k[d] < 1 || g->s[d] < 1 || g->p[d] < 0) return -1;
+    g->out_shape[d] = (in_shape[d] + 2 * g->p[d] - g->k[d]) / g->s[d] + 1;
+    if (g->out_shape[d] < 1) return -1;
+    g->kvol *= g->k[d];
+  }
+  if (subm)
+    for (int d = 0; d < 3; ++d)
+      if (!(g->k[d] & 1)) return -1;
+  return g->kvol <= 125 ? 0 : -1;
+}
+
+struct RbWs {
+  VxSlot* table;
+  long long cap;
+  unsigned* bitmap;
+  int* base;
+  long long nwords;
+  long long* total;
+  void* scan_ws;
+  size_t scan_bytes;
+  size_t bytes;
+};
+
+RbWs carve(void* basep, int64_t n_in, int batch, const int32_t* out_shape) {
+  RbWs w;
+  char* p = (char*)basep;
+  size_t o = 0;
+  auto take = [&](size_t b) {
+    char* r = p ? p + o : nullptr;
+    o += vx_align(b);
+    return r;
+  };
+  const int64_t nn = n_in > 0 ? n_in : 1;
+  w.cap = vx_hash_capacity(nn);
+  w.table = (VxSlot*)take(sizeof(VxSlot) * (size_t)w.cap);
+  w.total = (long long*)take(64);
+  w.nwords = 0;
+  w.bitmap = nullptr;
+  w.base = nullptr;
+  w.scan_ws = nullptr;
+  w.scan_bytes = 0;
+  if (out_shape) {
+    const long long cells = (long long)batch * out_shape[0] * out_shape[1] * out_shape[2];
+    w.nwords = (cells + 31) / 32;
+    w.bitmap = (unsigned*)take(4 * (size_t)w.nwords);
+    w.base = (int*)take(4 * (size_t)w.nwords);
+    w.scan_bytes = vx_scan_workspace_bytes(w.nwords);
+    w.scan_ws = take(w.scan_bytes);
+  }
+  w.bytes = o;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t vx_rulebook_workspace_bytes(int64_t n_in, int32_t batch,
+                                              const int32_t* out_shape) {
+  return carve(nullptr, n_in, batch, out_shape).bytes;
+}
+
+static int32_t build_table(const int32_t* d_coords, int64_t n, const ConvGeom& g, const RbWs& w,
+                           hipStream_t stream) {
+  hash_clear<<<(unsigned)vx_cdiv(w.cap, kThreads), kThreads, 0, stream>>>(w.table, w.cap);
+  VX_LAUNCH_CHECK();
+  hash_build<<<(unsigned)vx_cdiv(n, kThreads), kThreads, 0, stream>>>(d_coords, n, g, w.table,
+                                                                      w.cap - 1);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" int32_t vx_rulebook_subm(const int32_t* d_coords, int64_t n, int32_t batch,
+                                    const int32_t* shape, const int32_t* ksize, int32_t* d_nbr,
+                                    int64_t nbr_ld, void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(shape && ksize && d_ws, "rulebook_subm: null pointer");
+  VX_REQUIRE(n >= 0 && n < (1ll << 31) && batch >= 1, "rulebook_subm: bad n/batch");
+  ConvGeom g;
+  VX_REQUIRE(fill_geom(&g, shape, ksize, nullptr, nullptr, true) == 0,
+             "rulebook_subm: bad geometry (odd kernel sizes <= 125 offsets required)");
+  if (n == 0) return VX_OK;
+  VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm: bad table pointer / stride");
+  RbWs w = carve(d_ws, n, batch, nullptr);
+  if (ws_bytes < w.bytes) {
+    vx_set_error("rulebook_subm: workspace %zu < %zu", ws_bytes, w.bytes);
+    return VX_ERR_WORKSPACE;
+  }
+  int32_t rc = build_table(d_coords, n, g, w, stream);
+  if (rc) return rc;
+  dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)g.kvol);
+  subm_nbr<<<grid, kThreads, 0, stream>>>(d_coords, n, g, w.table, w.cap - 1, d_nbr, nbr_ld);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" int32_t vx_rulebook_conv_count(const int32_t* d_coords, int64_t n_in, int32_t batch,
+                                          const int32_t* in_shape, const int32_t* ksize,
+                                          const int32_t* stride, const int32_t* pad,
+                                          int32_t* out_shape, int64_t* h_n_out, void* d_ws,
+                                          size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(in_shape && ksize && stride && pad && out_shape && h_n_out && d_ws,
+             "rulebook_conv_count: null pointer");
+  VX_REQUIRE(n_in >= 0 && n_in < (1ll << 31) && batch >= 1, "rulebook_conv_count: bad n/batch");
+  ConvGeom g;
+  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false) == 0,
+             "rulebook_conv_count: bad geometry");
+  for (int d = 0; d < 3; ++d) out_shape[d] = g.out_shape[d];
+  *h_n_out = 0;
+  if (n_in == 0) return VX_OK;
+  VX_REQUIRE(d_coords, "rulebook_conv_count: null coords");
+  RbWs w = carve(d_ws, n_in, batch, g.out_shape);
+  if (ws_bytes < w.bytes) {
+    vx_set_error("rulebook_conv_count: workspace %zu < %zu", ws_bytes, w.bytes);
+    return VX_ERR_WORKSPACE;
+  }
+  VX_HIP(hipMemsetAsync(w.bitmap, 0, 4 * (size_t)w.nwords, stream));
+  conv_mark<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(d_coords, n_in, g,
+                                                                        w.bitmap);
+  VX_LAUNCH_CHECK();
+  bitmap_popc<<<(unsigned)vx_cdiv(w.nwords, kThreads), kThreads, 0, stream>>>(w.bitmap, w.nwords,
+                                                                              w.base);
+  VX_LAUNCH_CHECK();
+  int32_t rc = vx_scan_exclusive_i32(w.base, w.base, w.nwords, (int64_t*)w.total, w.scan_ws,
+                                     w.scan_bytes, stream);
+  if (rc) return rc;
+  VX_HIP(hipMemcpyAsync(h_n_out, w.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  VX_HIP(hipStreamSynchronize(stream));
+  return VX_OK;
+}
+
+extern "C" int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, int32_t batch,
+                                         const int32_t* in_shape, const int32_t* ksize,
+                                         const int32_t* stride, const int32_t* pad, int64_t n_out,
+                                         int32_t* d_out_coords, int32_t* d_nbr, int64_t nbr_ld,
+                                         int32_t* d_nbr_t, int64_t nbr_t_ld, void* d_ws,
+                                         size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(in_shape && ksize && stride && pad && d_ws, "rulebook_conv_emit: null pointer");
+  ConvGeom g;
+  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false) == 0,
+             "rulebook_conv_emit: bad geometry");
+  if (n_in == 0 || n_out == 0) return VX_OK;
+  VX_REQUIRE(d_coords && d_out_coords && d_nbr && nbr_ld >= n_out,
+             "rulebook_conv_emit: bad output pointers / stride");
+  VX_REQUIRE(!d_nbr_t || nbr_t_ld >= n_in, "rulebook_conv_emit: bad transpose stride");
+  RbWs w = carve(d_ws, n_in, batch, g.out_shape);
+  if (ws_bytes < w.bytes) {
+    vx_set_error("rulebook_conv_emit: workspace %zu < %zu", ws_bytes, w.bytes);
+    return VX_ERR_WORKSPACE;
+  }
+  conv_emit_coords<<<(unsigned)vx_cdiv(w.nwords, kThreads), kThreads, 0, stream>>>(
+      w.bitmap, w.base, w.nwords, g, d_out_coords);
+  VX_LAUNCH_CHECK();
+  int32_t rc = build_table(d_coords, n_in, g, w, stream);
+  if (rc) return rc;
+  if (d_nbr_t)
+    VX_HIP(hipMemsetAsync(d_nbr_t, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_t_ld, stream));
+  dim3 grid((unsigned)vx_cdiv(n_out, kThreads), (unsigned)g.kvol);
+  conv_nbr<<<grid, kThreads, 0, stream>>>(d_out_coords, n_out, g, w.table, w.cap - 1, d_nbr,
+                                          nbr_ld, d_nbr_t, nbr_t_ld);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" size_t vx_pairs_workspace_bytes(int32_t kvol, int64_t n_out) {
+  const int64_t nw = vx_cdiv(n_out > 0 ? n_out : 1, 64);
+  const size_t a = vx_align(4 * (size_t)kvol * (size_t)nw);
+  return 2 * a + vx_scan_workspace_bytes((int64_t)kvol * nw);
+}
+
+extern "C" int32_t vx_nbr_to_pairs(const int32_t* d_nbr, int64_t nbr_ld, int32_t kvol,
+                                   int64_t n_out, int32_t* d_pairs, int32_t* d_pair_num,
+                                   void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(kvol >= 1 && kvol <= 125 && n_out >= 0 && d_pair_num, "nbr_to_pairs: bad arguments");
+  if (n_out == 0) {
+    VX_HIP(hipMemsetAsync(d_pair_num, 0, 4 * (size_t)kvol, stream));
+    return VX_OK;
+  }
+  VX_REQUIRE(d_nbr && d_pairs && d_ws && nbr_ld >= n_out, "nbr_to_pairs: null pointer / stride");
+  if (ws_bytes < vx_pairs_workspace_bytes(kvol, n_out)) {
+    vx_set_error("nbr_to_pairs: workspace too small");
+    return VX_ERR_WORKSPACE;
+  }
+  const int64_t nw = vx_cdiv(n_out, 64);
+  const size_t a = vx_align(4 * (size_t)kvol * (size_t)nw);
+  int* wcnt = (int*)d_ws;
+  int* woff = (int*)((char*)d_ws + a);
+  void* sws = (char*)d_ws + 2 * a;
+  VX_HIP(hipMemsetAsync(d_pairs, 0xff, 4 * (size_t)kvol * 2 * (size_t)n_out, stream));
+  dim3 grid((unsigned)vx_cdiv(n_out, kThreads), (unsigned)kvol);
+  pairs_count<<<grid, kThreads, 0, stream>>>(d_nbr, nbr_ld, n_out, nw, wcnt);
+  VX_LAUNCH_CHECK();
+  int32_t rc = vx_scan_exclusive_i32(wcnt, woff, (int64_t)kvol * nw, nullptr, sws,
+                                     ws_bytes - 2 * a, stream);
+  if (rc) return rc;
+  pairs_write<<<grid, kThreads, 0, stream>>>(d_nbr, nbr_ld, n_out, nw, woff, d_pairs);
+  VX_LAUNCH_CHECK();
+  pairs_num<<<1, 128, 0, stream>>>(woff, wcnt, nw, kvol, d_pair_num);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's plugin interface for this path: the mean VFE reader and the
+two sparse backbones, composed from the `spconv.pytorch` API exactly as a user of the reference
+would (state_dict keys identical to the reference's modules).
+
+  VoxelFeatureExtractorV3  det3d/models/readers/voxel_encoder.py:197-211
+  SparseBasicBlock         det3d/models/backbones/scn.py:54-98
+  SpMiddleResNetFHD        det3d/models/backbones/scn.py:317-381
+  MultiViewBackbone        det3d/models/backbones/multiview.py:21-106
+Call signatures: reader(features, num_voxels, coors=None); backbone(voxel_features, coors,
+batch_size, input_shape) (det3d/models/detectors/ohs.py:57-66).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+import spconv.pytorch as spconv
+
+from .synth import BEV_LAYERS, RV_LAYERS, middle_layers
+
+
+def build_norm_layer(cfg, num_features):
+    """BN1d -> nn.BatchNorm1d(eps, momentum) (det3d/models/utils/norm.py:70-113); returns (name, layer)."""
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    if t != "BN1d":
+        raise KeyError(f"unsupported norm type {t} on the sparse path")
+    cfg.setdefault("eps", 1e-5)
+    layer = nn.BatchNorm1d(num_features, **cfg)
+    return "bn", layer
+
+
+class VoxelFeatureExtractorV3(nn.Module):
+    def __init__(self, num_input_features=4, norm_cfg=None, name="VoxelFeatureExtractorV3"):
+        super().__init__()
+        self.name = name
+        self.num_input_features = num_input_features
+
+    def forward(self, features, num_voxels, coors=None):
+        c = self.num_input_features
+        return (features[:, :, :c].sum(dim=1) / num_voxels.type_as(features).view(-1, 1)).contiguous()
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_cfg=None, downsample=None, indice_key=None):
+        super().__init__()
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-5, momentum=0.1)
+        # both convs carry a bias: the reference evaluates `norm_cfg is not None` after defaulting it
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, 3, stride=stride, padding=1, bias=True,
+                                       indice_key=indice_key)
+        self.bn1 = build_norm_layer(norm_cfg, planes)[1]
+        self.relu = nn.ReLU()
+        self.conv2 = spconv.SubMConv3d(planes, planes, 3, padding=1, bias=True, indice_key=indice_key)
+        self.bn2 = build_norm_layer(norm_cfg, planes)[1]
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.conv1(x)
+        y = y.replace_feature(self.relu(self.bn1(y.features)))
+        y = self.conv2(y)
+        y = y.replace_feature(self.bn2(y.features))
+        skip = x if self.downsample is None else self.downsample(x)
+        return y.replace_feature(self.relu(y.features + skip.features))
+
+
+_GEOM = {  # strided conv geometry per (cin, cout, ksize): (stride, padding)
+    (16, 32, (3, 3, 3)): (2, 1), (32, 64, (3, 3, 3)): (2, 1), (64, 128, (3, 3, 3)): (2, [0, 1, 1]),
+    (128, 128, (3, 1, 1)): ((2, 1, 1), 0), (128, 32, (1, 1, 3)): ((1, 1, 2), (0, 0, 1)),
+    (32, 32, (1, 1, 3)): ((1, 1, 2), (0, 0, 1)),
+}
+
+
+def _sequential(spec, norm_cfg, keys):
+    mods = []
+    keys = iter(keys)
+    key = None
+    for l in spec:
+        if l[0] == "subm":
+            key = next(keys)
+            mods.append(spconv.SubMConv3d(l[1], l[2], l[3], bias=False, indice_key=key))
+        elif l[0] == "conv":
+            st, pd = _GEOM[(l[1], l[2], tuple(l[3]))]
+            mods.append(spconv.SparseConv3d(l[1], l[2], l[3], st, padding=pd, bias=False))
+            key = next(keys)
+        elif l[0] == "bn":
+            mods.append(build_norm_layer(norm_cfg, l[1])[1])
+        elif l[0] == "relu":
+            mods.append(nn.ReLU())
+        elif l[0] == "block":
+            mods.append(SparseBasicBlock(l[1], l[1], norm_cfg=norm_cfg, indice_key=key))
+    return spconv.SparseSequential(*mods)
+
+
+class SpMiddleResNetFHD(nn.Module):
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
+        super().__init__()
+        self.name = name
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-5, momentum=0.1)
+        self.middle_conv = _sequential(middle_layers(num_input_features, True), norm_cfg,
+                                       ["res0", "res1", "res2", "res3", None])
+        self.mode = kwargs.get("mode", "bev")
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        x = spconv.SparseConvTensor(voxel_features, coors.int(), sparse_shape, batch_size)
+        ret = self.middle_conv(x).dense()
+        n, c, d, h, w = ret.shape
+        if self.mode == "bev":
+            ret = ret.view(n, c * d, h, w)
+        return ret
+
+
+class MultiViewBackbone(nn.Module):
+    def __init__(self, num_input_features=128, norm_cfg=None, name="MultiViewBackbone", **kwargs):
+        super().__init__()
+        self.name = name
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-5, momentum=0.1)
+        self.middle_conv = _sequential(middle_layers(num_input_features, False), norm_cfg,
+                                       ["res0", "res1", "res2", "res3"])
+        self.bev_conv = _sequential(BEV_LAYERS, norm_cfg, [None])
+        self.rv_conv = _sequential(RV_LAYERS, norm_cfg, ["res4", "res5", None])
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        x = spconv.SparseConvTensor(voxel_features, coors.int(), sparse_shape, batch_size)
+        mid = self.middle_conv(x)
+        bev = self.bev_conv(mid).dense()
+        n, c, d, h, w = bev.shape
+        bev = bev.view(n, c * d, h, w)
+        rv = self.rv_conv(mid).dense()
+        n, c, d, h, w = rv.shape
+        rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)
+        return bev, rv
+
+
+def load_numpy_state_dict(module, sd):
+    """Load a {name: ndarray} dict (vista_amd.synth.backbone_state_dict) strictly."""
+    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    for k, v in module.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            tsd[k] = v
+    module.load_state_dict(tsd, strict=True)
+    return module

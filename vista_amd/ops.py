@@ -1,0 +1,275 @@
+"""Torch-tensor front-ends of the libvx C-ABI (device pointers + the current stream).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and streams. Every op
+requires CUDA(HIP) tensors and raises otherwise: there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.VxError(f"{name} must be a CUDA/HIP tensor: this path has no CPU implementation")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_DT = {torch.float32: L.VX_F32, torch.bfloat16: L.VX_BF16}
+
+
+def triple(v):
+    if isinstance(v, (int, np.integer)):
+        return [int(v)] * 3
+    v = [int(x) for x in v]
+    if len(v) != 3:
+        raise ValueError(f"expected an int or a sequence of 3 ints, got {v}")
+    return v
+
+
+# ------------------------------------------------------------------------------------------------
+# voxelization + mean VFE
+# ------------------------------------------------------------------------------------------------
+def voxelize(points, voxel_size, pc_range, max_points, max_voxels, batch_idx=0,
+             with_voxels=False, with_mean=True):
+    """points f32[N,F] (cuda) -> dict(coords int32[M,4] (b,z,y,x), num_points int32[M],
+    voxels f32[M,T,F] | None, mean f32[M,F] | None). One host sync (reads M)."""
+    _need_gpu(points, "points")
+    if points.dtype != torch.float32 or points.dim() != 2:
+        raise ValueError("points must be float32 [N, F]")
+    points = points.contiguous()
+    n, f = points.shape
+    dev = points.device
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    rg = np.asarray(pc_range, dtype=np.float32)
+    if vs.shape != (3,) or rg.shape != (6,):
+        raise ValueError("voxel_size must have 3 and pc_range 6 entries")
+    cap = max(1, min(n, int(max_voxels)))
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
+    voxels = torch.empty((cap, max_points, f), dtype=torch.float32, device=dev) if with_voxels else None
+    mean = torch.empty((cap, f), dtype=torch.float32, device=dev) if with_mean else None
+    d_m = torch.zeros((1,), dtype=torch.int64, device=dev)
+    h_m = ctypes.c_int64(0)
+    lib = L.lib()
+    wsb = lib.vx_voxelize_workspace_bytes(n)
+    ws = _ws(wsb, dev)
+    with torch.cuda.device(dev):
+        rc = lib.vx_voxelize_hard(_ptr(points), n, f, vs.ctypes.data_as(L.c_f32p), rg.ctypes.data_as(L.c_f32p),
+                                  int(max_points), int(max_voxels), int(batch_idx), _ptr(coords), _ptr(nump),
+                                  _ptr(voxels), _ptr(mean), cap, _ptr(d_m), ctypes.byref(h_m), _ptr(ws), wsb,
+                                  _stream())
+    L.check(rc, "vx_voxelize_hard")
+    m = int(h_m.value)
+    return dict(coords=coords[:m], num_points=nump[:m],
+                voxels=voxels[:m] if voxels is not None else None,
+                mean=mean[:m] if mean is not None else None, num_voxels=m)
+
+
+# ------------------------------------------------------------------------------------------------
+# rulebooks
+# ------------------------------------------------------------------------------------------------
+class Rulebook:
+    """Output-major neighbour table nbr[k][o] (+ optional transpose) of one sparse conv geometry."""
+
+    def __init__(self, nbr, n_in, n_out, ksize, stride, padding, subm, in_shape, out_shape,
+                 out_indices, nbr_t=None):
+        self.nbr, self.nbr_t = nbr, nbr_t
+        self.n_in, self.n_out = n_in, n_out
+        self.ksize, self.stride, self.padding, self.subm = ksize, stride, padding, subm
+        self.in_shape, self.out_shape = list(in_shape), list(out_shape)
+        self.out_indices = out_indices
+        self.kvol = ksize[0] * ksize[1] * ksize[2]
+        self._pairs = None
+
+    def pairs(self):
+        """(indice_pairs int32[K,2,n_out], indice_pair_num int32[K]) -- spconv's pair-list view."""
+        if self._pairs is None:
+            self._pairs = nbr_to_pairs(self.nbr)
+        return self._pairs
+
+    @property
+    def indice_pairs(self):
+        return self.pairs()[0]
+
+    @property
+    def indice_pair_num(self):
+        return self.pairs()[1]
+
+    def transpose(self):
+        """nbr_t[k][i] = output row fed by input row i through offset k (strided convs)."""
+        if self.subm:
+            return self.nbr
+        if self.nbr_t is None:
+            k, n_out = self.nbr.shape
+            t = torch.full((k, max(self.n_in, 1)), -1, dtype=torch.int32, device=self.nbr.device)
+            kk, oo = torch.nonzero(self.nbr >= 0, as_tuple=True)
+            t[kk, self.nbr[kk, oo].long()] = oo.int()
+            self.nbr_t = t
+        return self.nbr_t
+
+
+def rulebook_subm(indices, batch_size, spatial_shape, ksize):
+    _need_gpu(indices, "indices")
+    if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4:
+        raise ValueError("indices must be int32 [N, 4] (batch, z, y, x)")
+    indices = indices.contiguous()
+    ks = triple(ksize)
+    n = indices.shape[0]
+    kvol = ks[0] * ks[1] * ks[2]
+    nbr = torch.empty((kvol, n), dtype=torch.int32, device=indices.device)
+    lib = L.lib()
+    wsb = lib.vx_rulebook_workspace_bytes(n, int(batch_size), None)
+    ws = _ws(wsb, indices.device)
+    with torch.cuda.device(indices.device):
+        rc = lib.vx_rulebook_subm(_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape), L.i32x3(ks),
+                                  _ptr(nbr), max(n, 1), _ptr(ws), wsb, _stream())
+    L.check(rc, "vx_rulebook_subm")
+    return Rulebook(nbr, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, spatial_shape, spatial_shape, indices)
+
+
+def conv_out_shape(in_shape, ksize, stride, padding):
+    ks, st, pd = triple(ksize), triple(stride), triple(padding)
+    return [(int(in_shape[d]) + 2 * pd[d] - ks[d]) // st[d] + 1 for d in range(3)]
+
+
+def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, transpose=False):
+    _need_gpu(indices, "indices")
+    if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4:
+        raise ValueError("indices must be int32 [N, 4] (batch, z, y, x)")
+    indices = indices.contiguous()
+    dev = indices.device
+    ks, st, pd = triple(ksize), triple(stride), triple(padding)
+    n = indices.shape[0]
+    kvol = ks[0] * ks[1] * ks[2]
+    osh_host = conv_out_shape(spatial_shape, ks, st, pd)
+    if min(osh_host) < 1:
+        raise ValueError(f"sparse conv output shape {osh_host} is empty")
+    lib = L.lib()
+    osh = L.i32x3(osh_host)
+    wsb = lib.vx_rulebook_workspace_bytes(n, int(batch_size), osh)
+    ws = _ws(wsb, dev)
+    h_n = ctypes.c_int64(0)
+    args = (_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape), L.i32x3(ks), L.i32x3(st), L.i32x3(pd))
+    with torch.cuda.device(dev):
+        rc = lib.vx_rulebook_conv_count(*args, osh, ctypes.byref(h_n), _ptr(ws), wsb, _stream())
+        L.check(rc, "vx_rulebook_conv_count")
+        n_out = int(h_n.value)
+        out_idx = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+        nbr = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
+        nbr_t = torch.empty((kvol, max(n, 1)), dtype=torch.int32, device=dev) if transpose else None
+        rc = lib.vx_rulebook_conv_emit(*args, n_out, _ptr(out_idx), _ptr(nbr), max(n_out, 1), _ptr(nbr_t),
+                                       max(n, 1), _ptr(ws), wsb, _stream())
+        L.check(rc, "vx_rulebook_conv_emit")
+    return Rulebook(nbr, n, n_out, ks, st, pd, False, spatial_shape, list(osh), out_idx, nbr_t)
+
+
+def nbr_to_pairs(nbr):
+    _need_gpu(nbr, "nbr")
+    kvol, n_out = nbr.shape
+    pairs = torch.empty((kvol, 2, n_out), dtype=torch.int32, device=nbr.device)
+    num = torch.empty((kvol,), dtype=torch.int32, device=nbr.device)
+    lib = L.lib()
+    wsb = lib.vx_pairs_workspace_bytes(kvol, n_out)
+    ws = _ws(wsb, nbr.device)
+    with torch.cuda.device(nbr.device):
+        rc = lib.vx_nbr_to_pairs(_ptr(nbr), max(n_out, 1), kvol, n_out, _ptr(pairs), _ptr(num), _ptr(ws), wsb,
+                                 _stream())
+    L.check(rc, "vx_nbr_to_pairs")
+    return pairs, num
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """features [n_in,Cin], weight [Cout,kz,ky,kx,Cin] (KRSC) -> [n_out,Cout]; fused epilogue
+    relu?((acc + bias) * scale + shift + residual)."""
+    _need_gpu(features, "features")
+    if features.dtype not in _DT:
+        raise ValueError(f"unsupported feature dtype {features.dtype}")
+    if weight.dtype != features.dtype:
+        raise ValueError("weight and features must share a dtype")
+    features = features.contiguous()
+    weight = weight.contiguous()
+    cout, cin = weight.shape[0], weight.shape[-1]
+    if features.dim() != 2 or features.shape[1] != cin or features.shape[0] != rb.n_in:
+        raise ValueError(f"features {tuple(features.shape)} do not match rulebook/weight ({rb.n_in}, {cin})")
+    if weight.numel() != cout * rb.kvol * cin:
+        raise ValueError("weight shape does not match the rulebook's kernel size")
+    out = torch.empty((rb.n_out, cout), dtype=features.dtype, device=features.device)
+    for t in (bias, scale, shift):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != cout or not t.is_cuda):
+            raise ValueError("bias/scale/shift must be float32 CUDA tensors of length Cout")
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.shape != out.shape or residual.dtype != out.dtype:
+            raise ValueError("residual must match the output shape and dtype")
+    with torch.cuda.device(features.device):
+        rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(rb.nbr),
+                                   max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
+                                   _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(out),
+                                   _DT[features.dtype], _stream())
+    L.check(rc, "vx_spconv_fwd")
+    return out
+
+
+def conv_dgrad(grad_out, weight, rb):
+    _need_gpu(grad_out, "grad_out")
+    grad_out = grad_out.contiguous()
+    weight = weight.contiguous()
+    cout, cin = weight.shape[0], weight.shape[-1]
+    din = torch.empty((rb.n_in, cin), dtype=grad_out.dtype, device=grad_out.device)
+    tbl = rb.transpose()
+    with torch.cuda.device(grad_out.device):
+        rc = L.lib().vx_spconv_dgrad(_ptr(grad_out), rb.n_out, cout, _ptr(weight), rb.kvol, cin, _ptr(tbl),
+                                     max(rb.n_in, 1), rb.n_in, 1 if rb.subm else 0, _ptr(din),
+                                     _DT[grad_out.dtype], _stream())
+    L.check(rc, "vx_spconv_dgrad")
+    return din
+
+
+def to_dense(features, indices, batch_size, spatial_shape):
+    """-> [B, C, D, H, W] (channels first, contiguous)."""
+    _need_gpu(features, "features")
+    features = features.contiguous()
+    indices = indices.contiguous()
+    n, c = features.shape
+    sh = triple(spatial_shape)
+    dense = torch.empty((int(batch_size), c, *sh), dtype=features.dtype, device=features.device)
+    with torch.cuda.device(features.device):
+        rc = L.lib().vx_to_dense(_ptr(features), _ptr(indices), n, c, int(batch_size), L.i32x3(sh), _ptr(dense),
+                                 _DT[features.dtype], _stream())
+    L.check(rc, "vx_to_dense")
+    return dense
+
+
+def conv_wgrad(features, grad_out, rb, weight_shape):
+    """-> dW float32 with the KRSC shape of the weight."""
+    _need_gpu(features, "features")
+    features = features.contiguous()
+    grad_out = grad_out.contiguous()
+    cout, cin = int(weight_shape[0]), int(weight_shape[-1])
+    pairs, num = rb.pairs()
+    dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=features.device)
+    lib = L.lib()
+    wsb = lib.vx_spconv_wgrad_workspace_bytes(cin, cout, rb.kvol, rb.n_out)
+    ws = _ws(wsb, features.device)
+    with torch.cuda.device(features.device):
+        rc = lib.vx_spconv_wgrad(_ptr(features), rb.n_in, cin, _ptr(grad_out), rb.n_out, cout, _ptr(pairs),
+                                 _ptr(num), rb.kvol, _ptr(dw), _DT[features.dtype], _ptr(ws), wsb, _stream())
+    L.check(rc, "vx_spconv_wgrad")
+    return dw

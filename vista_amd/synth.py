@@ -69,3 +69,71 @@ def backbone_weights(layer_shapes, seed: int = 1234):
         std = 1.0 / np.sqrt(kz * ky * kx * cin)
         ws.append(rng.normal(0.0, std, (cout, kz, ky, kx, cin)).astype(np.float32))
     return ws
+
+
+# ---------------------------------------------------------------------------
+# Seeded parameters, keyed by the reference's state_dict names
+# (backbone.middle_conv.<i>[.conv1|.bn1|...], scn.py:332-364, multiview.py:33-86).
+# ---------------------------------------------------------------------------
+def _seq_entries(prefix, layers):
+    """layers: list of ('subm'|'conv', cin, cout, ksize) | ('bn', c) | ('relu',) | ('block', c)."""
+    out = []
+    for i, l in enumerate(layers):
+        p = f"{prefix}.{i}"
+        if l[0] in ("subm", "conv"):
+            out.append((f"{p}.weight", ("w", l[1], l[2], l[3])))
+        elif l[0] == "bn":
+            out.append((p, ("bn", l[1])))
+        elif l[0] == "block":
+            c = l[1]
+            out.append((f"{p}.conv1.weight", ("w", c, c, (3, 3, 3))))
+            out.append((f"{p}.conv1.bias", ("b", c)))
+            out.append((f"{p}.bn1", ("bn", c)))
+            out.append((f"{p}.conv2.weight", ("w", c, c, (3, 3, 3))))
+            out.append((f"{p}.conv2.bias", ("b", c)))
+            out.append((f"{p}.bn2", ("bn", c)))
+    return out
+
+
+def middle_layers(cin=5, with_last=True):
+    L = [("subm", cin, 16, (3, 3, 3)), ("bn", 16), ("relu",), ("block", 16), ("block", 16),
+         ("conv", 16, 32, (3, 3, 3)), ("bn", 32), ("relu",), ("block", 32), ("block", 32),
+         ("conv", 32, 64, (3, 3, 3)), ("bn", 64), ("relu",), ("block", 64), ("block", 64),
+         ("conv", 64, 128, (3, 3, 3)), ("bn", 128), ("relu",), ("block", 128), ("block", 128)]
+    if with_last:
+        L += [("conv", 128, 128, (3, 1, 1)), ("bn", 128), ("relu",)]
+    return L
+
+
+BEV_LAYERS = [("conv", 128, 128, (3, 1, 1)), ("bn", 128), ("relu",)]
+RV_LAYERS = [("conv", 128, 32, (1, 1, 3)), ("bn", 32), ("relu",), ("block", 32),
+             ("conv", 32, 32, (1, 1, 3)), ("bn", 32), ("relu",), ("block", 32),
+             ("conv", 32, 32, (1, 1, 3)), ("bn", 32), ("relu",)]
+
+
+def backbone_state_dict(kind="SpMiddleResNetFHD", seed=1234, num_input_features=5):
+    """Ordered {name: float32 ndarray}. Conv weights KRSC [Cout,kz,ky,kx,Cin] ~ N(0, 1/sqrt(Kvol*Cin));
+    conv bias ~ N(0, 0.05); BN gamma~U(.5,1.5), beta~N(0,.1), mean~N(0,.1), var~U(.5,1.5)."""
+    if kind == "SpMiddleResNetFHD":
+        ents = _seq_entries("middle_conv", middle_layers(num_input_features, True))
+    elif kind == "MultiViewBackbone":
+        ents = (_seq_entries("middle_conv", middle_layers(num_input_features, False))
+                + _seq_entries("bev_conv", BEV_LAYERS) + _seq_entries("rv_conv", RV_LAYERS))
+    else:
+        raise ValueError(kind)
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, spec in ents:
+        if spec[0] == "w":
+            _, cin, cout, ks = spec
+            std = 1.0 / np.sqrt(ks[0] * ks[1] * ks[2] * cin)
+            sd[name] = rng.normal(0.0, std, (cout, *ks, cin)).astype(np.float32)
+        elif spec[0] == "b":
+            sd[name] = rng.normal(0.0, 0.05, (spec[1],)).astype(np.float32)
+        else:
+            c = spec[1]
+            sd[name + ".weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+            sd[name + ".bias"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+            sd[name + ".running_mean"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+            sd[name + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    return sd

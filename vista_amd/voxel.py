@@ -1,0 +1,91 @@
+"""GPU mirror of the reference's voxelization front-end (same names, argument meaning and outputs).
+
+  VoxelGenerator   det3d/core/input/voxel_generator.py:6-55
+  Voxelization     det3d/datasets/pipelines/preprocess.py:155-208 (dict contract only)
+  collate_voxels   det3d/torchie/parallel/collate.py:105-106,135-142 (batch assembly of the voxel keys)
+
+Inputs are CUDA float32 tensors [N, F]; outputs are CUDA tensors. In the reference this stage runs
+in DataLoader workers on the CPU; here it is a handful of HBM-bound kernels on the GPU.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class VoxelGenerator:
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, faster=True):
+        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        voxel_size = np.array(voxel_size, dtype=np.float32)
+        grid_size = (point_cloud_range[3:] - point_cloud_range[:3]) / voxel_size
+        self._grid_size = np.round(grid_size).astype(np.int64)
+        self._voxel_size = voxel_size
+        self._point_cloud_range = point_cloud_range
+        self._max_num_points = max_num_points
+        self._max_voxels = max_voxels
+        self.faster = faster  # both reference paths give identical results; one GPU path serves both
+
+    def generate(self, points, max_voxels=None):
+        """-> (voxels f32[M,T,F], coordinates int32[M,3] (z,y,x), num_points_per_voxel int32[M])."""
+        r = ops.voxelize(points, self._voxel_size, self._point_cloud_range, self._max_num_points,
+                         self._max_voxels, with_voxels=True, with_mean=False)
+        return r["voxels"], r["coords"][:, 1:], r["num_points"]
+
+    def generate_mean(self, points, batch_idx=0):
+        """Fused voxelization + mean VFE: -> (mean f32[M,F], coordinates int32[M,4] (b,z,y,x), num_points)."""
+        r = ops.voxelize(points, self._voxel_size, self._point_cloud_range, self._max_num_points,
+                         self._max_voxels, batch_idx=batch_idx, with_voxels=False, with_mean=True)
+        return r["mean"], r["coords"], r["num_points"]
+
+    @property
+    def voxel_size(self):
+        return self._voxel_size
+
+    @property
+    def max_num_points_per_voxel(self):
+        return self._max_num_points
+
+    @property
+    def point_cloud_range(self):
+        return self._point_cloud_range
+
+    @property
+    def grid_size(self):
+        return self._grid_size
+
+
+class Voxelization:
+    """Pipeline stage: res["lidar"]["points"] -> res["lidar"]["voxels"] dict (preprocess.py:202-208)."""
+
+    def __init__(self, **kwargs):
+        cfg = kwargs.get("cfg", None)
+        get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        self.range = get("range")
+        self.voxel_size = get("voxel_size")
+        self.max_points_in_voxel = get("max_points_in_voxel")
+        self.max_voxel_num = get("max_voxel_num")
+        self.faster = get("faster", False)
+        self.voxel_generator = VoxelGenerator(self.voxel_size, self.range, self.max_points_in_voxel,
+                                              self.max_voxel_num, self.faster)
+
+    def __call__(self, res, info):
+        voxels, coordinates, num_points = self.voxel_generator.generate(res["lidar"]["points"])
+        res["lidar"]["voxels"] = dict(
+            voxels=voxels, coordinates=coordinates, num_points=num_points,
+            num_voxels=np.array([voxels.shape[0]], dtype=np.int64), shape=self.voxel_generator.grid_size)
+        return res, info
+
+
+def collate_voxels(frames):
+    """frames: list of per-frame dicts from Voxelization -> batch dict with coordinates [sum M, 4] (b,z,y,x)."""
+    coords = [torch.nn.functional.pad(f["coordinates"], (1, 0), value=i) for i, f in enumerate(frames)]
+    return dict(voxels=torch.cat([f["voxels"] for f in frames]),
+                num_points=torch.cat([f["num_points"] for f in frames]),
+                num_voxels=np.concatenate([f["num_voxels"] for f in frames]),
+                coordinates=torch.cat(coords), shape=np.stack([f["shape"] for f in frames]))
+
+
+def voxelize_batch(generator, clouds):
+    """Fused path for a list of CUDA clouds: -> (mean f32[sum M,F], coords int32[sum M,4], num_points)."""
+    outs = [generator.generate_mean(c, batch_idx=b) for b, c in enumerate(clouds)]
+    return (torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
