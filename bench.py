@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- backbone frames/sec of the VISTA sparse voxel path on MI355X.
+
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+hard voxelization + mean VFE (fused) + SpMiddleResNetFHD forward (rulebooks, 21 sparse convs with
+fused BN/ReLU/residual epilogues, dense()). Workload = BASELINE.json configs[1]: FHD geometry
+(0.075 m, sparse_shape [41,1440,1440]), 10-sweep synthetic nuScenes-shaped frames (~247k points).
+
+Multi-GPU: frames are independent, so ranks shard frames with no data-path
+collective ("weak" scaling: fixed frames per GPU). `--mode train` runs the DDP backbone training
+step instead (fwd + bwd + RCCL gradient all-reduce + Adam).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from vista_amd import models, ops  # noqa: E402
+from vista_amd.engine import FusedBackbone  # noqa: E402
+from vista_amd.synth import GEOMETRIES, backbone_state_dict, grid_size, lidar_cloud  # noqa: E402
+from vista_amd.voxel import VoxelGenerator, voxelize_batch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--geometry", default="FHD", choices=["FHD", "VISTA", "STRESS"])
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    return ap.parse_args()
+
+
+def make_frames(geometry, batch, rank, dev):
+    sweeps = 40 if geometry == "STRESS" else 10
+    return [torch.from_numpy(lidar_cloud(seed=rank * batch + b, sweeps=sweeps)).to(dev) for b in range(batch)]
+
+
+def cpu_baseline(geometry):
+    """The oracle (a CPU port: numpy voxelizer + C/OpenMP sparse backbone) on ONE frame of the same workload."""
+    from oracle import backbone_oracle as bo
+    from oracle import spconv_oracle as so
+    from oracle import voxelize_np as ov
+    rg, vs, T, mv = GEOMETRIES[geometry]
+    pts = lidar_cloud(seed=0, sweeps=40 if geometry == "STRESS" else 10)
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+    threads = so.num_threads()
+    t0 = time.perf_counter()
+    v, c, n = ov.voxelize(pts, vs, rg, T, mv)
+    feat = ov.mean_vfe(v, n)
+    t1 = time.perf_counter()
+    out, _ = bo.sp_middle_resnet_fhd(feat, ov.collate_coords([c]), 1, grid_size(rg, vs).tolist(), sd)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 {geometry} frame (seed 0, {pts.shape[0]} points, {c.shape[0]} voxels): "
+                      f"voxelize+VFE {1e3 * (t1 - t0):.0f} ms (numpy, 1 thread), "
+                      f"backbone {1e3 * (t2 - t1):.0f} ms (C/OpenMP, {threads} threads)"}
+
+
+def timed_infer(gen, engine, frames, grid, steps, warmup, barrier):
+    def step():
+        mean, coords, _ = voxelize_batch(gen, frames)
+        return engine(mean, coords, len(frames), grid)
+    for _ in range(warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    ops.TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    timing, ops.TIMING = ops.TIMING, None
+    return dt, timing, out
+
+
+def dominant_kernel_roofline(timing, dtype):
+    """HIP-event time of every launch of the dominant conv kernel (Cin=Cout=128) in the timed region
+    vs its algorithmic FLOPs 2*pairs*Cin*Cout."""
+    sel = [t for t in timing if t["cin"] == 128 and t["cout"] == 128 and t["kvol"] == 27]
+    if not sel:
+        return None
+    ms = np.array([t["ev0"].elapsed_time(t["ev1"]) for t in sel])
+    pairs = {}
+    flops = []
+    for t in sel:
+        rb = t["rb"]
+        if id(rb) not in pairs:
+            pairs[id(rb)] = int((rb.nbr >= 0).sum().item())
+        flops.append(2.0 * pairs[id(rb)] * 128 * 128)
+    flops = np.array(flops)
+    achieved = float(flops.sum() / (ms.sum() * 1e-3) / 1e12)
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": None,
+            "kernel": "spconv_f32_kernel<128,128> (SubMConv3d 128->128, k=3)",
+            "launches": int(len(sel)), "avg_launch_ms": float(ms.mean()),
+            "flops_per_launch": float(flops.mean())}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if a.mode == "train":
+        from vista_amd.train import bench_train
+        res = bench_train(a, dev, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(res))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    rg, vs, T, mv = GEOMETRIES[a.geometry]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    dtype = torch.float32 if a.dtype == "fp32" else torch.bfloat16
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
+                                       backbone_state_dict("SpMiddleResNetFHD")).to(dev).eval()
+    engine = FusedBackbone(net, dtype=dtype)
+    frames = make_frames(a.geometry, a.batch, rank, dev)
+
+    dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_frames = world * a.batch * a.steps
+    res = {
+        "metric": "backbone frames/sec (voxelize + mean VFE + SpMiddleResNetFHD forward)",
+        "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"{a.geometry} 10-sweep synthetic nuScenes-shaped frames, sparse_shape "
+                               f"{[grid[2] + 1, grid[1], grid[0]]}, batch {a.batch}/GPU, inference, "
+                               "inputs resident in HBM (BASELINE.json configs[1])",
+                   "frames_per_gpu": a.batch, "points_per_frame": int(np.mean([f.shape[0] for f in frames])),
+                   "parallelism": f"frame-sharded x{world}"},
+    }
+    if rank == 0:
+        res["roofline"] = dominant_kernel_roofline(timing, a.dtype)
+        if world == 1 and not a.no_variants:
+            # batch-1 latency variant of the same workload (not part of `value`)
+            dt1, _, _ = timed_infer(gen, engine, frames[:1], grid, max(3, a.steps), 2, barrier)
+            res["variants"] = {"batch1_frames_per_s": max(3, a.steps) / dt1}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.geometry)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,8 @@ def rulebook_conv(coords, in_shape, ksize, stride, pad):
     K = k[0] * k[1] * k[2]
     n = coords.shape[0]
     osh = out_shape(in_shape, k, s, p)
+    if min(osh) < 1:
+        raise ValueError(f"sparse conv output shape {osh} is empty")
     if n == 0:
         return np.zeros((0, 4), np.int32), np.zeros((K, 0), np.int32), osh
     args = (_p(coords, c_i32p), ctypes.c_int64(n), _p(_i32(in_shape), c_i32p), _p(_i32(k), c_i32p),

@@ -1,0 +1,132 @@
+"""Inference engine for the sparse backbones: same results as running the nn.Module in eval mode,
+with BatchNorm1d(eval) + bias + ReLU + residual folded into the conv kernel's epilogue
+(scn.py:82-98 collapses from 2 GEMM sets + 4 elementwise passes to 2 launches per block) and all
+rulebooks of a frame built before the feature pass (they depend on coordinates only).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+import spconv.pytorch as spconv
+
+from . import ops
+from .models import SparseBasicBlock
+
+
+def _fold_bn(bn, dev):
+    g = bn.weight.detach().double()
+    b = bn.bias.detach().double()
+    inv = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+    scale = g * inv
+    shift = b - bn.running_mean.detach().double() * scale
+    return scale.float().to(dev).contiguous(), shift.float().to(dev).contiguous()
+
+
+class _Step:
+    __slots__ = ("kind", "w", "bias", "scale", "shift", "relu", "key", "ksize", "stride", "padding", "residual")
+
+
+def _compile_sequential(seq, dev, dtype):
+    """SparseSequential -> list of fused conv steps."""
+    mods = list(seq._modules.values())
+    steps = []
+    i = 0
+
+    def conv_step(conv, bn, relu, residual):
+        s = _Step()
+        s.kind = "subm" if conv.subm else "conv"
+        s.w = conv.weight.detach().to(dev, dtype).contiguous()
+        s.bias = conv.bias.detach().float().to(dev).contiguous() if conv.bias is not None else None
+        s.scale, s.shift = _fold_bn(bn, dev) if bn is not None else (None, None)
+        s.relu, s.key, s.residual = relu, conv.indice_key, residual
+        s.ksize, s.stride, s.padding = conv.kernel_size, conv.stride, conv.padding
+        return s
+
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, spconv.SparseConvolution):
+            bn = relu = None
+            j = i + 1
+            if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d):
+                bn = mods[j]
+                j += 1
+            if j < len(mods) and isinstance(mods[j], nn.ReLU):
+                relu = True
+                j += 1
+            steps.append(conv_step(m, bn, bool(relu), None))
+            i = j
+        elif isinstance(m, SparseBasicBlock):
+            if m.downsample is not None:
+                raise NotImplementedError("downsample blocks are not used by the VISTA backbones")
+            steps.append(conv_step(m.conv1, m.bn1, True, "save"))   # remembers its input as identity
+            steps.append(conv_step(m.conv2, m.bn2, True, "add"))
+            i += 1
+        else:
+            raise NotImplementedError(f"cannot fuse a bare {type(m).__name__} into the plan")
+    return steps
+
+
+class _State:
+    def __init__(self, feat, idx, shape, batch, cache):
+        self.feat, self.idx, self.shape, self.batch, self.cache = feat, idx, shape, batch, cache
+
+
+def _run(steps, st, geom_only=False):
+    st = _State(st.feat, st.idx, st.shape, st.batch, st.cache)
+    identity = None
+    for s in steps:
+        if s.kind == "subm":
+            rb = st.cache.get((s.key, id(st.idx)))
+            if rb is None:
+                rb = ops.rulebook_subm(st.idx, st.batch, st.shape, s.ksize)
+                st.cache[(s.key, id(st.idx))] = rb
+        else:
+            rb = st.cache.get(("conv", id(st.idx), tuple(s.ksize), tuple(s.stride), tuple(s.padding)))
+            if rb is None:
+                rb = ops.rulebook_conv(st.idx, st.batch, st.shape, s.ksize, s.stride, s.padding)
+                st.cache[("conv", id(st.idx), tuple(s.ksize), tuple(s.stride), tuple(s.padding))] = rb
+        if s.residual == "save":
+            identity = st.feat
+        res = identity if s.residual == "add" else None
+        if not geom_only:
+            st.feat = ops.conv_fwd(st.feat, s.w, rb, bias=s.bias, scale=s.scale, shift=s.shift,
+                                   residual=res, relu=s.relu)
+        if s.kind == "conv":
+            st.idx, st.shape = rb.out_indices, rb.out_shape
+    return st
+
+
+class FusedBackbone:
+    """Eval-mode forward of SpMiddleResNetFHD / MultiViewBackbone with fused epilogues."""
+
+    def __init__(self, module, dtype=torch.float32):
+        dev = next(module.parameters()).device
+        self.kind = type(module).__name__
+        self.dtype = dtype
+        self.mode = getattr(module, "mode", "bev")
+        self.middle = _compile_sequential(module.middle_conv, dev, dtype)
+        if self.kind == "MultiViewBackbone":
+            self.bev = _compile_sequential(module.bev_conv, dev, dtype)
+            self.rv = _compile_sequential(module.rv_conv, dev, dtype)
+        elif self.kind != "SpMiddleResNetFHD":
+            raise TypeError(f"unsupported backbone {self.kind}")
+
+    @torch.no_grad()
+    def __call__(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
+        st = _State(voxel_features.to(self.dtype), coors.int().contiguous(), sparse_shape, int(batch_size), {})
+        st.keep = st.idx
+        mid = _run(self.middle, st)
+        if self.kind == "SpMiddleResNetFHD":
+            d = ops.to_dense(mid.feat, mid.idx, mid.batch, mid.shape)
+            n, c, dd, h, w = d.shape
+            return d.view(n, c * dd, h, w) if self.mode == "bev" else d
+        b = _run(self.bev, mid)
+        bev = ops.to_dense(b.feat, b.idx, b.batch, b.shape)
+        n, c, d, h, w = bev.shape
+        bev = bev.view(n, c * d, h, w)
+        r = _run(self.rv, mid)
+        rv = ops.to_dense(r.feat, r.idx, r.batch, r.shape)
+        n, c, d, h, w = rv.shape
+        rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)
+        return bev, rv

@@ -30,6 +30,10 @@ def _ws(nbytes, device):
 
 _DT = {torch.float32: L.VX_F32, torch.bfloat16: L.VX_BF16}
 
+# bench.py sets this to a list to get HIP-event pairs (recorded on the launch stream) around every
+# conv_fwd launch; None (the default) records nothing.
+TIMING = None
+
 
 def triple(v):
     if isinstance(v, (int, np.integer)):
@@ -218,11 +222,19 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
         residual = residual.contiguous()
         if residual.shape != out.shape or residual.dtype != out.dtype:
             raise ValueError("residual must match the output shape and dtype")
+    rec = None
+    if TIMING is not None:
+        rec = dict(cin=cin, cout=cout, kvol=rb.kvol, rb=rb, ev0=torch.cuda.Event(enable_timing=True),
+                   ev1=torch.cuda.Event(enable_timing=True))
+        rec["ev0"].record()
     with torch.cuda.device(features.device):
         rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(rb.nbr),
                                    max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
                                    _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(out),
                                    _DT[features.dtype], _stream())
+    if rec is not None:
+        rec["ev1"].record()
+        TIMING.append(rec)
     L.check(rc, "vx_spconv_fwd")
     return out
 

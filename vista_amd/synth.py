@@ -15,7 +15,8 @@ GEOMETRIES = {
     "FHD": ([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.075, 0.075, 0.2], 10, 5_000_000),
     "VISTA": ([-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.08, 0.08, 0.08], 6, 5_000_000),
     "STRESS": ([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.05, 0.05, 0.2], 10, 5_000_000),
-    # small geometry for fast parity tests
+    # small geometries for fast parity tests (SMALL keeps 40 z cells so all 4 stride-2 stages exist)
+    "SMALL": ([-12.8, -12.8, -5.0, 12.8, 12.8, 3.0], [0.2, 0.2, 0.2], 5, 100_000),
     "TINY": ([-12.8, -12.8, -3.0, 12.8, 12.8, 1.0], [0.2, 0.2, 0.2], 5, 100_000),
 }
 
