@@ -121,9 +121,13 @@ int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, const void* d
                       const float* d_shift, const void* d_residual, int32_t flags, void* d_out,
                       int32_t dtype, void* stream);
 
-/* dgrad: din[i] = sum_k W[:,k,:]^T . dout[nbr_t[k][i]]  (input-stationary, atomic-free).
- * For a submanifold conv pass the forward table with subm=1 (nbr_t[k] == nbr[kvol-1-k]). */
-int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t cout, const void* d_weight,
+/* dgrad: din[i] = sum_k W[:,k,:]^T . dout[nbr_t[k][i]]  (input-stationary, atomic-free, same MFMA
+ * kernels as forward). d_weight_t is the TRANSPOSED weight copy [cin][kvol][cout]
+ * (weight.permute(4,1,2,3,0)). For a submanifold conv pass the forward table with subm=1
+ * (nbr_t[k] == nbr[kvol-1-k]); for a strided conv pass the transpose table of
+ * vx_rulebook_conv_emit. Replaces spconv's input gradient reached through autograd at
+ * det3d/core/utils/dist_utils.py:50-56 (loss.backward()). */
+int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t cout, const void* d_weight_t,
                         int32_t kvol, int32_t cin, const int32_t* d_nbr_t, int64_t nbr_t_ld,
                         int64_t n_in, int32_t subm, void* d_din, int32_t dtype, void* stream);
 

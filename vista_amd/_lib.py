@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvx.so")
+LIB_PATH = os.environ.get("VX_LIB", os.path.join(_HERE, "libvx.so"))  # VX_LIB: diagnostic builds only
 
 c_void_p, c_int32, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 c_f32p = ctypes.POINTER(ctypes.c_float)

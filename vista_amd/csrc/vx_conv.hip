@@ -2,20 +2,18 @@
 //
 //   out[o] = epi( sum_k  W_k . in[nbr[k][o]] )         nbr[k][o] = -1 -> no contribution
 //
-// One 256-thread workgroup owns 128 consecutive output rows (32 per wave) and all (<=128) output
-// channels; accumulators never leave registers, so there is no scatter, no atomic and the result
-// is bitwise reproducible. Per kernel offset k the workgroup stages W_k ([Cout][Cin], the KRSC
-// nn.Parameter layout) and each wave gathers its 32 input rows as whole rows (coalesced 16-byte
-// lanes) into LDS; offsets no row of the tile uses are skipped wave- and workgroup-uniformly.
-// MFMA: v_mfma_f32_32x32x2_f32, A = gathered rows, B = W_k^T. The reduction index is permuted so
-// that lane half h covers channels [h*Cin/2, (h+1)*Cin/2): both fragments are then contiguous
-// 16-byte LDS reads (ds_read_b128) from images padded to Cin+4 floats per row (conflict-free).
-//
-// The same kernel computes dgrad (roles of in/out swapped, W read transposed through strides).
+// Accumulators never leave registers: no scatter, no atomics, bitwise reproducible. MFMA is
+// v_mfma_f32_32x32x2_f32 (A = gathered rows, B = W_k^T); the reduction index is permuted so that
+// lane half h covers a contiguous half of the staged values, which makes every fragment a
+// contiguous 16-byte access. Two kernels:
+//   spconv_f32_w8      the hot path (cin in {8,16,32,64,128}, KRSC weights, kvol <= 32)
+//   spconv_f32_generic any cin <= 128 / strided weights (first layer cin=5): simple, LDS staged
+// dgrad runs on the same kernels with the roles of in/out swapped and a transposed weight copy.
 #include "vx_common.h"
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kTileRows = 128;  // rows per workgroup (32 per wave)
@@ -44,7 +42,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
 }
 
 template <int CIN_PAD, int COUT_PAD>
-__global__ __launch_bounds__(kThreads) void spconv_f32_kernel(ConvArgs a) {
+__global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
   constexpr int CP = CIN_PAD + 4;        // padded row length (floats)
   constexpr int NT = COUT_PAD / 32;      // 32-column accumulator tiles per wave
   constexpr int C4 = CIN_PAD / 4;        // float4 per row
@@ -160,11 +158,204 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_kernel(ConvArgs a) {
   }
 }
 
+
+constexpr int kKSlots = 32;  // index-table rows kept in LDS (kvol <= 32)
+
+// ------------------------------------------------------------------------------------------------
+// 8-wave kernel: 512 threads own 256 output rows; two waves share every SIMD so one wave's loads,
+// address arithmetic, LDS traffic and barrier waits hide under its partner's MFMAs.
+// The reduction runs in chunks of 64 staged values (C=128: half a kernel offset, C=64: one,
+// C=32: two, ...). Per chunk a lane holds its 32 gathered values in 8 VGPR quads, loaded straight
+// from HBM/L2 one chunk ahead (ping-pong register sets, no LDS for the gathered operand); missing
+// neighbours read a zero row, so no select is needed. The W chunk ([Cout][64], padded to 68) is
+// double buffered in LDS: one barrier per chunk.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) float vx_zero_row[128];  // zero-initialised
+
+constexpr int kW8Threads = 512;
+constexpr int kW8Rows = 256;
+
+template <int CIN, int COUT_PAD>
+__global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
+  constexpr int CK = 64, CPW = CK + 4;
+  constexpr int NT = COUT_PAD / 32;
+  constexpr int W_LD = (COUT_PAD * (CK / 4) + kW8Threads - 1) / kW8Threads;
+  constexpr int NW = kW8Threads / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int* sIdx = reinterpret_cast<int*>(smem + 2 * COUT_PAD * CPW) + wave * kKSlots * 32;
+  int* sMask = reinterpret_cast<int*>(smem + 2 * COUT_PAD * CPW) + NW * kKSlots * 32;
+
+  const int r = lane & 31, h = lane >> 5;
+  const long long tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long long row0 = tile * kW8Rows + wave * 32;
+  const int col0 = blockIdx.y * COUT_PAD;
+  const int nchunks = (a.kvol * CIN + CK - 1) / CK;
+
+  unsigned wmask = 0;
+#pragma unroll
+  for (int i = 0; i < kKSlots / 2; ++i) {
+    const int ks = 2 * i + h;
+    int idx = -1;
+    if (ks < a.kvol && row0 + r < a.n_out) {
+      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
+      idx = a.nbr[(long long)krow * a.ld + row0 + r];
+    }
+    sIdx[ks * 32 + r] = idx;
+    const unsigned long long b = __ballot(idx >= 0);
+    if ((unsigned)b) wmask |= 1u << (2 * i);
+    if ((unsigned)(b >> 32)) wmask |= 1u << (2 * i + 1);
+  }
+  if (lane == 0) sMask[wave] = (int)wmask;
+  __syncthreads();
+  unsigned gmask = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) gmask |= (unsigned)sMask[i];
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  // kernel offsets touched by chunk c: [c*64/CIN, (c*64+63)/CIN]
+  auto chunk_used = [&](unsigned m, int c) {
+    const int g0 = c * CK / CIN;
+    constexpr int span = (CK + CIN - 1) / CIN;  // offsets per chunk (1 when CIN >= 64)
+    constexpr unsigned bits = (span >= 32) ? 0xffffffffu : ((1u << span) - 1u);
+    return ((m >> g0) & bits) != 0u;
+  };
+  auto next_chunk = [&](int c) {
+    ++c;
+    while (c < nchunks && !chunk_used(gmask, c)) ++c;
+    return c;
+  };
+
+  f32x4 r0[8], r1[8], rw[W_LD];
+
+  auto load_a = [&](int c, f32x4(&dst)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int P = c * CK + h * 32 + 4 * q;
+      const int g = P / CIN, ch = P % CIN;
+      const int idx = sIdx[g * 32 + r];   // slots >= kvol hold -1
+      const float* src = idx >= 0 ? a.in + (long long)idx * CIN + ch : vx_zero_row + ch;
+      dst[q] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kW8Threads + (int)threadIdx.x;
+      const int oc = e / (CK / 4), q = e % (CK / 4);
+      const int P = c * CK + 4 * q;
+      const int g = P / CIN, ch = P % CIN;
+      const int goc = col0 + oc;
+      const bool ok = goc < a.cout && g < a.kvol && oc < COUT_PAD;
+      const float* src = ok ? a.w + ((long long)goc * a.kvol + g) * CIN + ch : vx_zero_row;
+      rw[t] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_w = [&](int buf) {
+    float* sW = smem + buf * COUT_PAD * CPW;
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kW8Threads + (int)threadIdx.x;
+      const int oc = e / (CK / 4), q = e % (CK / 4);
+      if (oc < COUT_PAD) *reinterpret_cast<f32x4*>(sW + oc * CPW + q * 4) = rw[t];
+    }
+  };
+  auto mfma_chunk = [&](int buf, const f32x4(&ra)[8]) {
+    const float* pb = smem + buf * COUT_PAD * CPW + r * CPW + h * (CK / 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f32x4 bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * CPW + 4 * j);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].x, bv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].y, bv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].z, bv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].w, bv[t].w, acc[t], 0, 0, 0);
+    }
+  };
+  // one pipeline step: chunk c is in `cur` + sW[buf]; prefetch chunk cn into `nxt` + sW[buf^1]
+  auto step = [&](int c, int cn, int buf, const f32x4(&cur)[8], f32x4(&nxt)[8]) {
+    const bool more = cn < nchunks;
+    if (more) {
+      load_w(cn);
+      if (chunk_used(wmask, cn)) load_a(cn, nxt);
+    }
+    if (chunk_used(wmask, c)) mfma_chunk(buf, cur);
+    if (more) store_w(buf ^ 1);
+    __syncthreads();
+  };
+
+  int c = next_chunk(-1);
+  if (c < nchunks) {
+    load_w(c);
+    if (chunk_used(wmask, c)) load_a(c, r0);
+    store_w(0);
+  }
+  __syncthreads();
+  while (c < nchunks) {
+    const int c1 = next_chunk(c);
+    step(c, c1, 0, r0, r1);
+    if (c1 >= nchunks) break;
+    const int c2 = next_chunk(c1);
+    step(c1, c2, 1, r1, r0);
+    c = c2;
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + r;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.0f;
+    const float sc = a.scale ? a.scale[col] : 1.0f;
+    const float sh = a.shift ? a.shift[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (row >= a.n_out) continue;
+      float v = acc[t][i] + b;
+      if (a.scale || a.shift) v = v * sc + sh;
+      if (a.residual) v += a.residual[row * a.cout + col];
+      if (a.relu) v = fmaxf(v, 0.0f);
+      a.out[row * a.cout + col] = v;
+    }
+  }
+}
+
+template <int CIN, int COUT_PAD>
+int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * COUT_PAD * (64 + 4) * sizeof(float) +
+                         (size_t)(kW8Threads / 64) * kKSlots * 32 * sizeof(int) + 64;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = spconv_f32_w8<CIN, COUT_PAD>;
+  VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds));
+  dim3 grid((unsigned)vx_cdiv(a.n_out, kW8Rows), (unsigned)vx_cdiv(a.cout, COUT_PAD));
+  kern<<<grid, kW8Threads, lds, stream>>>(a);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+template <int CIN>
+int32_t dispatch_w8_cout(const ConvArgs& a, hipStream_t s) {
+  if (a.cout <= 32) return launch_w8<CIN, 32>(a, s);
+  if (a.cout <= 64) return launch_w8<CIN, 64>(a, s);
+  return launch_w8<CIN, 128>(a, s);
+}
+
 template <int CIN_PAD, int COUT_PAD>
 int32_t launch(const ConvArgs& a, hipStream_t stream) {
   constexpr size_t lds = (size_t)(COUT_PAD + kTileRows) * (CIN_PAD + 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = spconv_f32_kernel<CIN_PAD, COUT_PAD>;
+  auto kern = spconv_f32_generic<CIN_PAD, COUT_PAD>;
   if (lds > 64 * 1024)
     VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
@@ -182,6 +373,20 @@ int32_t dispatch_cout(const ConvArgs& a, hipStream_t s) {
 }
 
 int32_t dispatch(const ConvArgs& a, hipStream_t s) {
+  const bool fast = (a.cin & 3) == 0 && a.w_si == 1 && a.w_sk == a.cin &&
+                    a.w_so == (long long)a.kvol * a.cin && a.kvol <= kKSlots &&
+                    (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+  if (fast) {
+    switch (a.cin) {
+      case 8: return dispatch_w8_cout<8>(a, s);
+      case 16: return dispatch_w8_cout<16>(a, s);
+      case 32: return dispatch_w8_cout<32>(a, s);
+      case 64: return dispatch_w8_cout<64>(a, s);
+      case 128: return dispatch_w8_cout<128>(a, s);
+      default: break;
+    }
+  }
   if (a.cin <= 8) return dispatch_cout<8>(a, s);
   if (a.cin <= 16) return dispatch_cout<16>(a, s);
   if (a.cin <= 32) return dispatch_cout<32>(a, s);
@@ -236,10 +441,10 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   VX_REQUIRE(d_weight && d_nbr_t && d_din && nbr_t_ld >= n_in, "spconv_dgrad: null pointer/stride");
   ConvArgs a;
   a.in = (const float*)d_dout;            // gathered operand: dout rows, cout channels
-  a.w = (const float*)d_weight;           // W[co][k][ci] read as (oc = ci, ic = co)
-  a.w_so = 1;
-  a.w_sk = cin;
-  a.w_si = (long long)kvol * cin;
+  a.w = (const float*)d_weight;           // transposed copy Wt[ci][k][co]: (oc = ci, ic = co)
+  a.w_so = (long long)kvol * cout;
+  a.w_sk = cout;
+  a.w_si = 1;
   a.nbr = d_nbr_t;
   a.ld = nbr_t_ld;
   a.n_out = n_in;

@@ -242,8 +242,8 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
 def conv_dgrad(grad_out, weight, rb):
     _need_gpu(grad_out, "grad_out")
     grad_out = grad_out.contiguous()
-    weight = weight.contiguous()
     cout, cin = weight.shape[0], weight.shape[-1]
+    weight = weight.permute(4, 1, 2, 3, 0).contiguous()  # [Cin, kz, ky, kx, Cout]
     din = torch.empty((rb.n_in, cin), dtype=grad_out.dtype, device=grad_out.device)
     tbl = rb.transpose()
     with torch.cuda.device(grad_out.device):
