@@ -1,0 +1,58 @@
+"""CPU, world_size 2 over gloo: the N>1 logic of the path (frame sharding + flat-bucket gradient
+averaging). The sparse kernels themselves need a GPU; the collectives and bookkeeping do not."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vista_amd.train import allreduce_grads_flat, shard_frames
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    data = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    mine = shard_frames(8, rank, world)
+    loss = (net(data[mine]) ** 2).sum() / 8.0 * world   # so that the rank-average equals the global mean loss
+    loss.backward()
+    nbytes = allreduce_grads_flat(list(net.parameters()), dist, world)
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    q.put((rank, mine, nbytes, flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_equals_single_process_gradient():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res[0][1] + res[1][1]) == list(range(8))
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    data = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    ((net(data) ** 2).sum() / 8.0).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert res[0][2] == ref.numel() * 4
+    for _, _, _, flat in res:
+        assert torch.allclose(flat, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(res[0][3], res[1][3])      # both ranks hold identical averaged gradients
