@@ -108,13 +108,32 @@ def dominant_kernel_roofline(timing, dtype):
             pairs[id(rb)] = int((rb.nbr >= 0).sum().item())
         flops.append(2.0 * pairs[id(rb)] * 128 * 128)
     flops = np.array(flops)
-    achieved = float(flops.sum() / (ms.sum() * 1e-3) / 1e12)
-    peak = PEAK_F32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": None,
-            "kernel": "spconv_f32_kernel<128,128> (SubMConv3d 128->128, k=3)",
-            "launches": int(len(sel)), "avg_launch_ms": float(ms.mean()),
-            "flops_per_launch": float(flops.mean())}
+    tflops = float(flops.sum() / (ms.sum() * 1e-3) / 1e12)
+    common = {"launches": int(len(sel)), "avg_launch_ms": float(ms.mean()), "flops_per_launch": float(flops.mean()),
+              "achieved_tflops": tflops}
+    if dtype == "fp32":
+        # fp32: intensity Cout/2 = 64 flop per gathered byte -> MFMA-bound (157.3 TFLOP/s fp32 matrix peak)
+        return {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("f32"),
+                "kernel": "spconv_w8<float,128,128> (SubMConv3d 128->128, k=3)", **common}
+    # bf16: MFMA is 16x faster, the gather phase bounds the layer (bytes = pairs*Cin*s + N_out*Cout*s
+    # + K*Cin*Cout*s + pairs*8, s = 2)
+    nbytes = np.array([p_ * 128 * 2 + t["rb"].n_out * 128 * 2 + 27 * 128 * 128 * 2 + p_ * 8
+                       for t, p_ in zip(sel, [pairs[id(t["rb"])] for t in sel])], dtype=np.float64)
+    gbs = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
+    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "traffic": pmc_traffic("bf16"), "kernel": "spconv_w8<bf16,128,128> (SubMConv3d 128->128, k=3)",
+            "bytes_per_launch": float(nbytes.mean()), **common}
+
+
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if absent."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))
+        return d["dominant_kernel"][dtype]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():

@@ -383,3 +383,44 @@ def test_backbone_train_step_grads_vs_oracle(dev):
         stage = int(n.split(".")[1])
         assert rel <= (1e-3 if stage >= 15 else 5e-2), (n, rel)
         assert cos >= 0.9995, (n, cos)
+
+
+# ---------------------------------------------------------------------------- bf16
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 64), (64, 64), (128, 128), (128, 32)])
+def test_conv_fwd_bf16_vs_oracle(cin, cout, dev):
+    """bf16 in/weights/out, fp32 accumulate. Oracle fed the SAME bf16-rounded operands, so the only
+    differences are accumulation order and the final bf16 rounding of the output (<= 2^-8 relative)."""
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    shape = [9, 40, 40]
+    coords = random_sites(rng, 2, shape, 1500)
+    feat = torch.from_numpy(rng.normal(size=(coords.shape[0], cin)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rng.normal(size=(cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)).bfloat16()
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    nbr = so.rulebook_subm(coords, shape, 3)
+    ref = so.conv_fwd(feat.float().numpy(), w.float().numpy(), nbr, bias)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    got = ops.conv_fwd(feat.to(dev), w.to(dev), rb, bias=torch.from_numpy(bias).to(dev))
+    assert got.dtype == torch.bfloat16
+    err = np.abs(got.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err <= 5e-3, err
+
+
+def test_backbone_forward_bf16_vs_oracle(dev):
+    """north_star tolerance for bf16: 2e-2 relative against the fp32 CPU oracle."""
+    from oracle import backbone_oracle as bo
+    from oracle import voxelize_np as ov
+    from vista_amd import models
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import backbone_state_dict
+    clouds, mean, coords, grid, (rg, vs, T, mv) = _tiny_frames(dev, 2)
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).to(dev).eval()
+    ovx = [ov.voxelize(c, vs, rg, T, mv) for c in clouds]
+    ref, _ = bo.sp_middle_resnet_fhd(np.concatenate([ov.mean_vfe(v, n) for v, c, n in ovx]),
+                                     ov.collate_coords([c for v, c, n in ovx]), 2, grid, sd)
+    out = FusedBackbone(net, dtype=torch.bfloat16)(mean, coords, 2, grid)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == ref.shape
+    err = np.abs(out.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err <= 2e-2, err

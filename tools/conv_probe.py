@@ -8,6 +8,7 @@ from vista_amd.synth import GEOMETRIES, grid_size, lidar_cloud
 from vista_amd.voxel import VoxelGenerator, voxelize_batch
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 dev = torch.device("cuda:0")
 rg, vs, T, mv = GEOMETRIES["FHD"]
 gen = VoxelGenerator(vs, rg, T, mv)
@@ -25,10 +26,10 @@ for name, cin, cout, k, s, p in [("conv1", 16, 32, 3, 2, 1), ("conv2", 32, 64, 3
     rbs = ops.rulebook_subm(idx, batch, shape, 3)
     stages.append(("subm" + name[-1], cout, cout, rbs))
 rng = np.random.default_rng(0)
-print(f"lib={os.environ.get('VX_LIB', 'libvx.so')} batch={batch}")
+print(f"lib={os.environ.get('VX_LIB', 'libvx.so')} batch={batch} dtype={dt}")
 for name, cin, cout, rb in stages:
-    x = torch.from_numpy(rng.normal(size=(rb.n_in, cin)).astype(np.float32)).to(dev)
-    w = torch.from_numpy((rng.normal(size=(cout, *rb.ksize, cin)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev)
+    x = torch.from_numpy(rng.normal(size=(rb.n_in, cin)).astype(np.float32)).to(dev).to(dt)
+    w = torch.from_numpy((rng.normal(size=(cout, *rb.ksize, cin)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev).to(dt)
     pairs = int((rb.nbr >= 0).sum().item())
     for _ in range(2):
         ops.conv_fwd(x, w, rb)
@@ -41,4 +42,4 @@ for name, cin, cout, rb in stages:
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * pairs * cin * cout
     print(f"{name:6s} {cin:3d}->{cout:3d} n_out={rb.n_out:8d} pairs={pairs:9d} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  "
-          f"gather {pairs * cin * 4 / ms / 1e6:7.1f} GB/s")
+          f"gather {pairs * cin * x.element_size() / ms / 1e6:7.1f} GB/s")

@@ -33,6 +33,7 @@ struct ConvArgs {
   const float* residual;  // [n_out][cout] or null
   int relu;
   float* out;           // [n_out][cout]
+  int dtype;            // VX_F32 | VX_BF16 (element type of in / w / residual / out)
 };
 
 // bijective XCD-aware remap: consecutive tiles (which share gathered neighbours) run on one XCD
@@ -162,29 +163,75 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 constexpr int kKSlots = 32;  // index-table rows kept in LDS (kvol <= 32)
 
 // ------------------------------------------------------------------------------------------------
-// 8-wave kernel: 512 threads own 256 output rows; two waves share every SIMD so one wave's loads,
-// address arithmetic, LDS traffic and barrier waits hide under its partner's MFMAs.
-// The reduction runs in chunks of 64 staged values (C=128: half a kernel offset, C=64: one,
-// C=32: two, ...). Per chunk a lane holds its 32 gathered values in 8 VGPR quads, loaded straight
-// from HBM/L2 one chunk ahead (ping-pong register sets, no LDS for the gathered operand); missing
-// neighbours read a zero row, so no select is needed. The W chunk ([Cout][64], padded to 68) is
-// double buffered in LDS: one barrier per chunk.
+// 8-wave kernel (hot path), fp32 and bf16.
+// 512 threads own 256 output rows; two waves share every SIMD so one wave's loads, address
+// arithmetic, LDS traffic and barrier waits hide under its partner's MFMAs.
+// The reduction runs in chunks of 256 staged BYTES per row (64 fp32 / 128 bf16 values; C=128 fp32:
+// half a kernel offset ... C=16 bf16: 8 offsets). Per chunk a lane holds 128 contiguous bytes of
+// its row's neighbours in 8 VGPR quads, loaded straight from HBM/L2 one chunk ahead (ping-pong
+// register sets, no LDS for the gathered operand); missing neighbours read a zero row, so no
+// select is needed. The W chunk ([Cout][256 B], rows padded to 272 B: conflict-free ds_read_b128)
+// is double buffered in LDS: one barrier per chunk. A 16-byte quad feeds 4 v_mfma_f32_32x32x2_f32
+// (fp32) or 1 v_mfma_f32_32x32x16_bf16 (bf16); accumulation is fp32 in both.
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(256))) float vx_zero_row[128];  // zero-initialised
+__device__ __attribute__((aligned(256))) float vx_zero_row[128];  // zero-initialised, 512 B
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kW8Threads = 512;
 constexpr int kW8Rows = 256;
+constexpr int kRowBytes = 256;          // staged bytes per row per chunk
+constexpr int kRowPad = kRowBytes + 16; // LDS row pitch
 
-template <int CIN, int COUT_PAD>
-__global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
-  constexpr int CK = 64, CPW = CK + 4;
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int VPQ = 4;  // values per 16-byte quad
+  template <int NT>
+  static __device__ __forceinline__ void mma(const f32x4& av, const f32x4 (&bv)[NT], f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+  }
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<__bf16> {
+  static constexpr int VPQ = 8;
+  template <int NT>
+  static __device__ __forceinline__ void mma(const f32x4& av, const f32x4 (&bv)[NT], f32x16 (&acc)[NT]) {
+    const bf16x8 a8 = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, bv[t]), acc[t], 0, 0, 0);
+  }
+  static __device__ __forceinline__ float load(const __bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void store(__bf16* p, float v) { *p = (__bf16)v; }
+};
+
+template <typename T, int CIN, int COUT_PAD>
+__global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
+  constexpr int VPQ = Elem<T>::VPQ;
+  constexpr int CK = kRowBytes / (int)sizeof(T);      // staged values per chunk (64 / 128)
+  constexpr int QPR = kRowBytes / 16;                 // quads per W row (16)
   constexpr int NT = COUT_PAD / 32;
-  constexpr int W_LD = (COUT_PAD * (CK / 4) + kW8Threads - 1) / kW8Threads;
+  constexpr int W_LD = (COUT_PAD * QPR + kW8Threads - 1) / kW8Threads;
   constexpr int NW = kW8Threads / 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(CIN % VPQ == 0, "a quad must not straddle two neighbour rows");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int* sIdx = reinterpret_cast<int*>(smem + 2 * COUT_PAD * CPW) + wave * kKSlots * 32;
-  int* sMask = reinterpret_cast<int*>(smem + 2 * COUT_PAD * CPW) + NW * kKSlots * 32;
+  int* sIdx = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPad) + wave * kKSlots * 32;
+  int* sMask = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPad) + NW * kKSlots * 32;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wgt = reinterpret_cast<const T*>(a.w);
+  const T* zero = reinterpret_cast<const T*>(vx_zero_row);
 
   const int r = lane & 31, h = lane >> 5;
   const long long tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -218,10 +265,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-  // kernel offsets touched by chunk c: [c*64/CIN, (c*64+63)/CIN]
+  // kernel offsets touched by chunk c: [c*CK/CIN, (c*CK+CK-1)/CIN]
   auto chunk_used = [&](unsigned m, int c) {
     const int g0 = c * CK / CIN;
-    constexpr int span = (CK + CIN - 1) / CIN;  // offsets per chunk (1 when CIN >= 64)
+    constexpr int span = (CK + CIN - 1) / CIN;
     constexpr unsigned bits = (span >= 32) ? 0xffffffffu : ((1u << span) - 1u);
     return ((m >> g0) & bits) != 0u;
   };
@@ -236,10 +283,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
   auto load_a = [&](int c, f32x4(&dst)[8]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int P = c * CK + h * 32 + 4 * q;
+      const int P = c * CK + h * (CK / 2) + VPQ * q;   // staged value position
       const int g = P / CIN, ch = P % CIN;
-      const int idx = sIdx[g * 32 + r];   // slots >= kvol hold -1
-      const float* src = idx >= 0 ? a.in + (long long)idx * CIN + ch : vx_zero_row + ch;
+      const int idx = g < kKSlots ? sIdx[g * 32 + r] : -1;   // slots >= kvol hold -1
+      const T* src = idx >= 0 ? in + (long long)idx * CIN + ch : zero;
       dst[q] = *reinterpret_cast<const f32x4*>(src);
     }
   };
@@ -247,39 +294,32 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < W_LD; ++t) {
       const int e = t * kW8Threads + (int)threadIdx.x;
-      const int oc = e / (CK / 4), q = e % (CK / 4);
-      const int P = c * CK + 4 * q;
+      const int oc = e / QPR, q = e % QPR;
+      const int P = c * CK + VPQ * q;
       const int g = P / CIN, ch = P % CIN;
       const int goc = col0 + oc;
       const bool ok = goc < a.cout && g < a.kvol && oc < COUT_PAD;
-      const float* src = ok ? a.w + ((long long)goc * a.kvol + g) * CIN + ch : vx_zero_row;
+      const T* src = ok ? wgt + ((long long)goc * a.kvol + g) * CIN + ch : zero;
       rw[t] = *reinterpret_cast<const f32x4*>(src);
     }
   };
   auto store_w = [&](int buf) {
-    float* sW = smem + buf * COUT_PAD * CPW;
+    char* sW = smem_raw + buf * COUT_PAD * kRowPad;
 #pragma unroll
     for (int t = 0; t < W_LD; ++t) {
       const int e = t * kW8Threads + (int)threadIdx.x;
-      const int oc = e / (CK / 4), q = e % (CK / 4);
-      if (oc < COUT_PAD) *reinterpret_cast<f32x4*>(sW + oc * CPW + q * 4) = rw[t];
+      const int oc = e / QPR, q = e % QPR;
+      if (oc < COUT_PAD) *reinterpret_cast<f32x4*>(sW + oc * kRowPad + q * 16) = rw[t];
     }
   };
   auto mfma_chunk = [&](int buf, const f32x4(&ra)[8]) {
-    const float* pb = smem + buf * COUT_PAD * CPW + r * CPW + h * (CK / 2);
+    const char* pb = smem_raw + buf * COUT_PAD * kRowPad + r * kRowPad + h * (kRowBytes / 2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       f32x4 bv[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * CPW + 4 * j);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].x, bv[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].y, bv[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].z, bv[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].w, bv[t].w, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * kRowPad + 16 * j);
+      Elem<T>::template mma<NT>(ra[j], bv, acc);
     }
   };
   // one pipeline step: chunk c is in `cur` + sW[buf]; prefetch chunk cn into `nxt` + sW[buf^1]
@@ -310,6 +350,9 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
     c = c2;
   }
 
+  // ---- epilogue: bias, per-channel affine (folded BatchNorm), residual, ReLU ---------------------
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.residual);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = col0 + t * 32 + r;
@@ -323,19 +366,19 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_f32_w8(ConvArgs a) {
       if (row >= a.n_out) continue;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
-      if (a.residual) v += a.residual[row * a.cout + col];
+      if (res) v += Elem<T>::load(res + row * a.cout + col);
       if (a.relu) v = fmaxf(v, 0.0f);
-      a.out[row * a.cout + col] = v;
+      Elem<T>::store(out + row * a.cout + col, v);
     }
   }
 }
 
-template <int CIN, int COUT_PAD>
+template <typename T, int CIN, int COUT_PAD>
 int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
-  constexpr size_t lds = (size_t)2 * COUT_PAD * (64 + 4) * sizeof(float) +
+  constexpr size_t lds = (size_t)2 * COUT_PAD * kRowPad +
                          (size_t)(kW8Threads / 64) * kKSlots * 32 * sizeof(int) + 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = spconv_f32_w8<CIN, COUT_PAD>;
+  auto kern = spconv_w8<T, CIN, COUT_PAD>;
   VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
   dim3 grid((unsigned)vx_cdiv(a.n_out, kW8Rows), (unsigned)vx_cdiv(a.cout, COUT_PAD));
@@ -344,11 +387,23 @@ int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   return VX_OK;
 }
 
-template <int CIN>
+template <typename T, int CIN>
 int32_t dispatch_w8_cout(const ConvArgs& a, hipStream_t s) {
-  if (a.cout <= 32) return launch_w8<CIN, 32>(a, s);
-  if (a.cout <= 64) return launch_w8<CIN, 64>(a, s);
-  return launch_w8<CIN, 128>(a, s);
+  if (a.cout <= 32) return launch_w8<T, CIN, 32>(a, s);
+  if (a.cout <= 64) return launch_w8<T, CIN, 64>(a, s);
+  return launch_w8<T, CIN, 128>(a, s);
+}
+
+template <typename T>
+int32_t dispatch_w8(const ConvArgs& a, hipStream_t s) {
+  switch (a.cin) {
+    case 8: return dispatch_w8_cout<T, 8>(a, s);
+    case 16: return dispatch_w8_cout<T, 16>(a, s);
+    case 32: return dispatch_w8_cout<T, 32>(a, s);
+    case 64: return dispatch_w8_cout<T, 64>(a, s);
+    case 128: return dispatch_w8_cout<T, 128>(a, s);
+    default: return 1;  // not eligible
+  }
 }
 
 template <int CIN_PAD, int COUT_PAD>
@@ -373,19 +428,16 @@ int32_t dispatch_cout(const ConvArgs& a, hipStream_t s) {
 }
 
 int32_t dispatch(const ConvArgs& a, hipStream_t s) {
-  const bool fast = (a.cin & 3) == 0 && a.w_si == 1 && a.w_sk == a.cin &&
-                    a.w_so == (long long)a.kvol * a.cin && a.kvol <= kKSlots &&
-                    (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+  const bool fast = a.w_si == 1 && a.w_sk == a.cin && a.w_so == (long long)a.kvol * a.cin &&
+                    a.kvol <= kKSlots && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
   if (fast) {
-    switch (a.cin) {
-      case 8: return dispatch_w8_cout<8>(a, s);
-      case 16: return dispatch_w8_cout<16>(a, s);
-      case 32: return dispatch_w8_cout<32>(a, s);
-      case 64: return dispatch_w8_cout<64>(a, s);
-      case 128: return dispatch_w8_cout<128>(a, s);
-      default: break;
-    }
+    const int32_t rc = a.dtype == VX_BF16 ? dispatch_w8<__bf16>(a, s) : dispatch_w8<float>(a, s);
+    if (rc <= 0) return rc;
+  }
+  if (a.dtype != VX_F32) {
+    vx_set_error("spconv: bf16 needs cin in {8,16,32,64,128}, contiguous KRSC weights and kvol <= 32");
+    return VX_ERR_ARG;
   }
   if (a.cin <= 8) return dispatch_cout<8>(a, s);
   if (a.cin <= 16) return dispatch_cout<16>(a, s);
@@ -400,7 +452,7 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
                                  int64_t n_out, const float* d_bias, const float* d_scale,
                                  const float* d_shift, const void* d_residual, int32_t flags,
                                  void* d_out, int32_t dtype, void* stream) {
-  VX_REQUIRE(dtype == VX_F32, "spconv_fwd: only VX_F32 is built in this revision");
+  VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "spconv_fwd: dtype must be VX_F32 or VX_BF16");
   VX_REQUIRE(cin >= 1 && cin <= 128 && cout >= 1 && kvol >= 1 && kvol <= 125,
              "spconv_fwd: need 1 <= cin <= 128, cout >= 1, 1 <= kvol <= 125");
   VX_REQUIRE(n_in >= 0 && n_out >= 0, "spconv_fwd: negative size");
@@ -426,6 +478,7 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
   a.residual = (const float*)d_residual;
   a.relu = (flags & VX_EPI_RELU) ? 1 : 0;
   a.out = (float*)d_out;
+  a.dtype = dtype;
   return dispatch(a, (hipStream_t)stream);
 }
 
@@ -433,7 +486,7 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
                                    const void* d_weight, int32_t kvol, int32_t cin,
                                    const int32_t* d_nbr_t, int64_t nbr_t_ld, int64_t n_in,
                                    int32_t subm, void* d_din, int32_t dtype, void* stream) {
-  VX_REQUIRE(dtype == VX_F32, "spconv_dgrad: only VX_F32 is built in this revision");
+  VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "spconv_dgrad: dtype must be VX_F32 or VX_BF16");
   VX_REQUIRE(cout >= 1 && cout <= 128 && cin >= 1 && kvol >= 1 && kvol <= 125,
              "spconv_dgrad: need 1 <= cout <= 128, cin >= 1, 1 <= kvol <= 125");
   VX_REQUIRE(n_in >= 0 && n_out >= 0, "spconv_dgrad: negative size");
@@ -455,5 +508,6 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.bias = a.scale = a.shift = a.residual = nullptr;
   a.relu = 0;
   a.out = (float*)d_din;
+  a.dtype = dtype;
   return dispatch(a, (hipStream_t)stream);
 }

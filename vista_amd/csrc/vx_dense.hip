@@ -8,11 +8,13 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRows = 64;
 
-__global__ __launch_bounds__(kThreads) void to_dense_f32(const float* __restrict__ feat,
-                                                         const int* __restrict__ coords,
-                                                         long long n, int c, int d, int hh, int ww,
-                                                         float* __restrict__ dense) {
-  extern __shared__ float tile[];  // [kRows][c + 1]
+template <typename T>  // moved as raw 4- or 2-byte words (fp32 / bf16)
+__global__ __launch_bounds__(kThreads) void to_dense_kernel(const T* __restrict__ feat,
+                                                            const int* __restrict__ coords,
+                                                            long long n, int c, int d, int hh, int ww,
+                                                            T* __restrict__ dense) {
+  extern __shared__ __attribute__((aligned(16))) char tile_raw[];
+  T* tile = reinterpret_cast<T*>(tile_raw);  // [kRows][c + 1]
   const int cp = c + 1;
   const long long row0 = (long long)blockIdx.x * kRows;
   const int rows = (int)((n - row0) < kRows ? (n - row0) : kRows);
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(kThreads) void to_dense_f32(const float* __restrict
   const int4 q = *reinterpret_cast<const int4*>(coords + 4 * (row0 + lane));
   const long long vol = (long long)d * hh * ww;
   const long long sp = ((long long)q.y * hh + q.z) * ww + q.w;
-  float* dst = dense + (long long)q.x * c * vol + sp;
+  T* dst = dense + (long long)q.x * c * vol + sp;
   for (int cc = wave; cc < c; cc += kThreads / 64) dst[(long long)cc * vol] = tile[lane * cp + cc];
 }
 }  // namespace
@@ -35,15 +37,21 @@ extern "C" int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int6
                                int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
                                void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  VX_REQUIRE(dtype == VX_F32, "to_dense: only VX_F32 is built in this revision");
+  VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "to_dense: dtype must be VX_F32 or VX_BF16");
+  const size_t esz = dtype == VX_F32 ? 4 : 2;
   VX_REQUIRE(shape && d_dense && batch >= 1 && c >= 1 && c <= 4096 && n >= 0, "to_dense: bad arguments");
   const size_t total = (size_t)batch * c * shape[0] * shape[1] * shape[2];
-  VX_HIP(hipMemsetAsync(d_dense, 0, total * sizeof(float), stream));
+  VX_HIP(hipMemsetAsync(d_dense, 0, total * esz, stream));
   if (n == 0) return VX_OK;
   VX_REQUIRE(d_feat && d_coords, "to_dense: null pointer");
-  const size_t lds = (size_t)kRows * (c + 1) * sizeof(float);
-  to_dense_f32<<<(unsigned)vx_cdiv(n, kRows), kThreads, lds, stream>>>(
-      (const float*)d_feat, d_coords, n, c, shape[0], shape[1], shape[2], (float*)d_dense);
+  const size_t lds = (size_t)kRows * (c + 1) * esz;
+  const unsigned grid = (unsigned)vx_cdiv(n, kRows);
+  if (dtype == VX_F32)
+    to_dense_kernel<uint32_t><<<grid, kThreads, lds, stream>>>(
+        (const uint32_t*)d_feat, d_coords, n, c, shape[0], shape[1], shape[2], (uint32_t*)d_dense);
+  else
+    to_dense_kernel<uint16_t><<<grid, kThreads, lds, stream>>>(
+        (const uint16_t*)d_feat, d_coords, n, c, shape[0], shape[1], shape[2], (uint16_t*)d_dense);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }

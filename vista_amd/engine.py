@@ -23,7 +23,7 @@ def _fold_bn(bn, dev):
 
 
 class _Step:
-    __slots__ = ("kind", "w", "bias", "scale", "shift", "relu", "key", "ksize", "stride", "padding", "residual")
+    __slots__ = ("kind", "w", "w32", "bias", "scale", "shift", "relu", "key", "ksize", "stride", "padding", "residual")
 
 
 def _compile_sequential(seq, dev, dtype):
@@ -36,6 +36,7 @@ def _compile_sequential(seq, dev, dtype):
         s = _Step()
         s.kind = "subm" if conv.subm else "conv"
         s.w = conv.weight.detach().to(dev, dtype).contiguous()
+        s.w32 = conv.weight.detach().to(dev, torch.float32).contiguous() if conv.in_channels % 8 else None
         s.bias = conv.bias.detach().float().to(dev).contiguous() if conv.bias is not None else None
         s.scale, s.shift = _fold_bn(bn, dev) if bn is not None else (None, None)
         s.relu, s.key, s.residual = relu, conv.indice_key, residual
@@ -89,8 +90,14 @@ def _run(steps, st, geom_only=False):
             identity = st.feat
         res = identity if s.residual == "add" else None
         if not geom_only:
-            st.feat = ops.conv_fwd(st.feat, s.w, rb, bias=s.bias, scale=s.scale, shift=s.shift,
+            w = s.w
+            if st.feat.dtype != w.dtype:
+                # first layer: the voxelizer's fp32 means (Cin=5) run through the fp32 kernel
+                w = s.w32
+            st.feat = ops.conv_fwd(st.feat, w, rb, bias=s.bias, scale=s.scale, shift=s.shift,
                                    residual=res, relu=s.relu)
+            if st.feat.dtype != s.w.dtype:
+                st.feat = st.feat.to(s.w.dtype)
         if s.kind == "conv":
             st.idx, st.shape = rb.out_indices, rb.out_shape
     return st
@@ -114,8 +121,7 @@ class FusedBackbone:
     @torch.no_grad()
     def __call__(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
-        st = _State(voxel_features.to(self.dtype), coors.int().contiguous(), sparse_shape, int(batch_size), {})
-        st.keep = st.idx
+        st = _State(voxel_features, coors.int().contiguous(), sparse_shape, int(batch_size), {})
         mid = _run(self.middle, st)
         if self.kind == "SpMiddleResNetFHD":
             d = ops.to_dense(mid.feat, mid.idx, mid.batch, mid.shape)
