@@ -91,12 +91,21 @@ int32_t vx_rulebook_conv_count(const int32_t* d_coords, int64_t n_in, int32_t ba
 
 /* strided conv, phase 2 (same workspace, untouched since phase 1): output coordinates sorted by
  * linear index ((b*D+z)*H+y)*W+x, the neighbour table, and optionally its transpose
- * d_nbr_t[k][i] = output row fed by input row i through offset k, or -1 (row stride nbr_t_ld). */
+ * d_nbr_t[k][i] = output row fed by input row i through offset k, or -1 (row stride nbr_t_ld).
+ * d_rank (optional, vx_rank_table_bytes(batch, out_shape) bytes): receives the rank table of the
+ * OUTPUT set ({occupancy bits, row base} per 32 cells) for vx_rulebook_subm_ranked. */
 int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, int32_t batch,
                               const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
                               const int32_t* pad, int64_t n_out, int32_t* d_out_coords,
                               int32_t* d_nbr, int64_t nbr_ld, int32_t* d_nbr_t, int64_t nbr_t_ld,
-                              void* d_workspace, size_t workspace_bytes, void* stream);
+                              void* d_rank, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* submanifold rulebook over a site set that carries a rank table (the outputs of a strided conv):
+ * coordinate -> row is one 8-byte read + popcount instead of a hash probe; no workspace. */
+size_t vx_rank_table_bytes(int32_t batch, const int32_t* shape);
+int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, int32_t batch,
+                                const int32_t* shape, const int32_t* ksize, const void* d_rank,
+                                int32_t* d_nbr, int64_t nbr_ld, void* stream);
 
 /* pair-list view (spconv's indice_pairs): d_pairs int32[K][2][n_out] ((in,out) per offset, ordered
  * by output row, -1 padded), d_pair_num int32[K]. Wavefront-ballot compaction. */

@@ -119,7 +119,8 @@ class SparseConvolution(SparseModule):
                 return rb
             raise ValueError(f"indice_key {self.indice_key}: cached rulebook does not match this layer")
         if self.subm:
-            rb = vx.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size)
+            rb = vx.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
+                                  rank=getattr(x, "rank_table", None))
         else:
             rb = vx.rulebook_conv(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
                                   self.padding, transpose=torch.is_grad_enabled())
@@ -140,6 +141,7 @@ class SparseConvolution(SparseModule):
                                input.spatial_shape if self.subm else rb.out_shape, input.batch_size,
                                input.grid, input.voxel_num, input.indice_dict, input.benchmark)
         out.benchmark_record = input.benchmark_record
+        out.rank_table = input.rank_table if self.subm else rb.out_rank
         return out
 
 

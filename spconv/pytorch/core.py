@@ -31,6 +31,9 @@ class SparseConvTensor:
         self.voxel_num = voxel_num
         self.benchmark = benchmark
         self.benchmark_record = {}
+        # libvx extra: rank table of `indices` (set by strided convs, whose outputs are sorted rows);
+        # lets SubMConv3d build its rulebook without a hash table. None for user-built tensors.
+        self.rank_table = None
 
     @property
     def features(self):
@@ -46,6 +49,7 @@ class SparseConvTensor:
         t = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.grid,
                              self.voxel_num, self.indice_dict, self.benchmark)
         t.benchmark_record = self.benchmark_record
+        t.rank_table = self.rank_table
         return t
 
     @property

@@ -31,7 +31,10 @@ SIGNATURES = {
                                          c_i32p, c_i64p, c_void_p, c_size_t, c_void_p]),
     "vx_rulebook_conv_emit": (c_int32, [c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_i32p, c_i32p,
                                         c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                        c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_rank_table_bytes": (c_size_t, [c_int32, c_i32p]),
+    "vx_rulebook_subm_ranked": (c_int32, [c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_void_p, c_void_p,
+                                          c_int64, c_void_p]),
     "vx_pairs_workspace_bytes": (c_size_t, [c_int32, c_int64]),
     "vx_nbr_to_pairs": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

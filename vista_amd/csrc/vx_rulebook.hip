@@ -110,23 +110,65 @@ __global__ __launch_bounds__(kThreads) void conv_emit_coords(const unsigned* __r
   }
 }
 
-__global__ __launch_bounds__(kThreads) void conv_nbr(const int* __restrict__ out_coords,
-                                                     long long n_out, ConvGeom g,
-                                                     const VxSlot* __restrict__ t, long long mask,
-                                                     int* __restrict__ nbr, long long ld,
-                                                     int* __restrict__ nbr_t, long long ld_t) {
+// rank table entry: 32 cells of the (sorted) active set; row(key) = base + popc(bits below key)
+__device__ __forceinline__ int rank_lookup(const uint2* __restrict__ rank, long long key) {
+  const uint2 e = rank[key >> 5];
+  const unsigned bit = (unsigned)key & 31u;
+  if (!((e.x >> bit) & 1u)) return -1;
+  return (int)e.y + __popc(e.x & ((1u << bit) - 1u));
+}
+
+__global__ __launch_bounds__(kThreads) void rank_interleave(const unsigned* __restrict__ bitmap,
+                                                            const int* __restrict__ base,
+                                                            long long nwords, uint2* __restrict__ rank) {
+  long long w = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (w < nwords) rank[w] = make_uint2(bitmap[w], (unsigned)base[w]);
+}
+
+// strided conv phase 2, from the INPUT side: every input enumerates the (<= 8 of 27 for k3/s2)
+// outputs it feeds, finds their rows in the rank table and writes both tables. The output table
+// was pre-filled with -1; the transpose table gets every (k, i) entry written here (coalesced).
+__global__ __launch_bounds__(kThreads) void conv_pairs_from_inputs(
+    const int* __restrict__ coords, long long n, ConvGeom g, const uint2* __restrict__ rank,
+    int* __restrict__ nbr, long long ld, int* __restrict__ nbr_t, long long ld_t) {
+  long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  for (int kz = 0; kz < g.k[0]; ++kz) {
+    const int tz = c.y + g.p[0] - kz;
+    const bool vz = tz >= 0 && (tz % g.s[0]) == 0 && (tz / g.s[0]) < g.out_shape[0];
+    for (int ky = 0; ky < g.k[1]; ++ky) {
+      const int ty = c.z + g.p[1] - ky;
+      const bool vy = vz && ty >= 0 && (ty % g.s[1]) == 0 && (ty / g.s[1]) < g.out_shape[1];
+      for (int kx = 0; kx < g.k[2]; ++kx) {
+        const int k = (kz * g.k[1] + ky) * g.k[2] + kx;
+        const int tx = c.w + g.p[2] - kx;
+        int row = -1;
+        if (vy && tx >= 0 && (tx % g.s[2]) == 0 && (tx / g.s[2]) < g.out_shape[2]) {
+          row = rank_lookup(rank, lin_idx(c.x, tz / g.s[0], ty / g.s[1], tx / g.s[2], g.out_shape));
+          if (row >= 0) nbr[(long long)k * ld + row] = (int)i;
+        }
+        if (nbr_t) nbr_t[(long long)k * ld_t + i] = row;
+      }
+    }
+  }
+}
+
+// submanifold rulebook over a set that carries a rank table (outputs of a strided conv: sorted rows)
+__global__ __launch_bounds__(kThreads) void subm_nbr_ranked(const int* __restrict__ coords,
+                                                            long long n, ConvGeom g,
+                                                            const uint2* __restrict__ rank,
+                                                            int* __restrict__ nbr, long long ld) {
   const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
   const int k = blockIdx.y;
-  if (o >= n_out) return;
+  if (o >= n) return;
   const int kx = k % g.k[2], ky = (k / g.k[2]) % g.k[1], kz = k / (g.k[2] * g.k[1]);
-  const int4 c = *reinterpret_cast<const int4*>(out_coords + 4 * o);
-  const int z = c.y * g.s[0] - g.p[0] + kz, y = c.z * g.s[1] - g.p[1] + ky,
-            x = c.w * g.s[2] - g.p[2] + kx;
+  const int4 c = *reinterpret_cast<const int4*>(coords + 4 * o);
+  const int z = c.y + kz - g.k[0] / 2, y = c.z + ky - g.k[1] / 2, x = c.w + kx - g.k[2] / 2;
   int r = -1;
   if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2])
-    r = vx_hash_find(t, mask, lin_idx(c.x, z, y, x, g.in_shape));
+    r = rank_lookup(rank, lin_idx(c.x, z, y, x, g.in_shape));
   nbr[(long long)k * ld + o] = r;
-  if (nbr_t && r >= 0) nbr_t[(long long)k * ld_t + r] = (int)o;
 }
 
 // ---- pair-list view: wavefront-ballot compaction ------------------------------------------------
@@ -186,6 +228,7 @@ int fill_geom(ConvGeom* g, const int32_t* in_shape, const int32_t* ksize, const 
 
 struct RbWs {
   VxSlot* table;
+  void* rank_tmp;
   long long cap;
   unsigned* bitmap;
   int* base;
@@ -207,7 +250,8 @@ RbWs carve(void* basep, int64_t n_in, int batch, const int32_t* out_shape) {
   };
   const int64_t nn = n_in > 0 ? n_in : 1;
   w.cap = vx_hash_capacity(nn);
-  w.table = (VxSlot*)take(sizeof(VxSlot) * (size_t)w.cap);
+  w.table = out_shape ? nullptr : (VxSlot*)take(sizeof(VxSlot) * (size_t)w.cap);  // subm only
+  w.rank_tmp = nullptr;
   w.total = (long long*)take(64);
   w.nwords = 0;
   w.bitmap = nullptr;
@@ -219,6 +263,7 @@ RbWs carve(void* basep, int64_t n_in, int batch, const int32_t* out_shape) {
     w.nwords = (cells + 31) / 32;
     w.bitmap = (unsigned*)take(4 * (size_t)w.nwords);
     w.base = (int*)take(4 * (size_t)w.nwords);
+    w.rank_tmp = take(8 * (size_t)w.nwords);
     w.scan_bytes = vx_scan_workspace_bytes(w.nwords);
     w.scan_ws = take(w.scan_bytes);
   }
@@ -306,8 +351,8 @@ extern "C" int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, 
                                          const int32_t* in_shape, const int32_t* ksize,
                                          const int32_t* stride, const int32_t* pad, int64_t n_out,
                                          int32_t* d_out_coords, int32_t* d_nbr, int64_t nbr_ld,
-                                         int32_t* d_nbr_t, int64_t nbr_t_ld, void* d_ws,
-                                         size_t ws_bytes, void* stream_) {
+                                         int32_t* d_nbr_t, int64_t nbr_t_ld, void* d_rank,
+                                         void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   VX_REQUIRE(in_shape && ksize && stride && pad && d_ws, "rulebook_conv_emit: null pointer");
   ConvGeom g;
@@ -322,16 +367,39 @@ extern "C" int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, 
     vx_set_error("rulebook_conv_emit: workspace %zu < %zu", ws_bytes, w.bytes);
     return VX_ERR_WORKSPACE;
   }
-  conv_emit_coords<<<(unsigned)vx_cdiv(w.nwords, kThreads), kThreads, 0, stream>>>(
-      w.bitmap, w.base, w.nwords, g, d_out_coords);
+  const unsigned gw = (unsigned)vx_cdiv(w.nwords, kThreads);
+  conv_emit_coords<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, g, d_out_coords);
   VX_LAUNCH_CHECK();
-  int32_t rc = build_table(d_coords, n_in, g, w, stream);
-  if (rc) return rc;
-  if (d_nbr_t)
-    VX_HIP(hipMemsetAsync(d_nbr_t, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_t_ld, stream));
-  dim3 grid((unsigned)vx_cdiv(n_out, kThreads), (unsigned)g.kvol);
-  conv_nbr<<<grid, kThreads, 0, stream>>>(d_out_coords, n_out, g, w.table, w.cap - 1, d_nbr,
-                                          nbr_ld, d_nbr_t, nbr_t_ld);
+  // rank table {bits, base}: caller's buffer when it wants to keep it, else the hash area of the workspace
+  uint2* rank = d_rank ? (uint2*)d_rank : (uint2*)w.rank_tmp;
+  rank_interleave<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, rank);
+  VX_LAUNCH_CHECK();
+  VX_HIP(hipMemsetAsync(d_nbr, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_ld, stream));
+  conv_pairs_from_inputs<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(
+      d_coords, n_in, g, rank, d_nbr, nbr_ld, d_nbr_t, nbr_t_ld);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" size_t vx_rank_table_bytes(int32_t batch, const int32_t* shape) {
+  const long long cells = (long long)batch * shape[0] * shape[1] * shape[2];
+  return (size_t)((cells + 31) / 32) * 8;
+}
+
+extern "C" int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, int32_t batch,
+                                           const int32_t* shape, const int32_t* ksize,
+                                           const void* d_rank, int32_t* d_nbr, int64_t nbr_ld,
+                                           void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(shape && ksize && d_rank, "rulebook_subm_ranked: null pointer");
+  VX_REQUIRE(n >= 0 && n < (1ll << 31) && batch >= 1, "rulebook_subm_ranked: bad n/batch");
+  ConvGeom g;
+  VX_REQUIRE(fill_geom(&g, shape, ksize, nullptr, nullptr, true) == 0,
+             "rulebook_subm_ranked: bad geometry (odd kernel sizes <= 125 offsets required)");
+  if (n == 0) return VX_OK;
+  VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm_ranked: bad table pointer / stride");
+  dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)g.kvol);
+  subm_nbr_ranked<<<grid, kThreads, 0, stream>>>(d_coords, n, g, (const uint2*)d_rank, d_nbr, nbr_ld);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }

@@ -68,18 +68,19 @@ def _compile_sequential(seq, dev, dtype):
 
 
 class _State:
-    def __init__(self, feat, idx, shape, batch, cache):
+    def __init__(self, feat, idx, shape, batch, cache, rank=None):
         self.feat, self.idx, self.shape, self.batch, self.cache = feat, idx, shape, batch, cache
+        self.rank = rank  # rank table of idx when idx came out of a strided conv
 
 
 def _run(steps, st, geom_only=False):
-    st = _State(st.feat, st.idx, st.shape, st.batch, st.cache)
+    st = _State(st.feat, st.idx, st.shape, st.batch, st.cache, st.rank)
     identity = None
     for s in steps:
         if s.kind == "subm":
             rb = st.cache.get((s.key, id(st.idx)))
             if rb is None:
-                rb = ops.rulebook_subm(st.idx, st.batch, st.shape, s.ksize)
+                rb = ops.rulebook_subm(st.idx, st.batch, st.shape, s.ksize, rank=st.rank)
                 st.cache[(s.key, id(st.idx))] = rb
         else:
             rb = st.cache.get(("conv", id(st.idx), tuple(s.ksize), tuple(s.stride), tuple(s.padding)))
@@ -99,7 +100,7 @@ def _run(steps, st, geom_only=False):
             if st.feat.dtype != s.w.dtype:
                 st.feat = st.feat.to(s.w.dtype)
         if s.kind == "conv":
-            st.idx, st.shape = rb.out_indices, rb.out_shape
+            st.idx, st.shape, st.rank = rb.out_indices, rb.out_shape, rb.out_rank
     return st
 
 

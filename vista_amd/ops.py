@@ -98,6 +98,7 @@ class Rulebook:
         self.out_indices = out_indices
         self.kvol = ksize[0] * ksize[1] * ksize[2]
         self._pairs = None
+        self.out_rank = None  # rank table of the output site set (strided convs): see rulebook_subm
 
     def pairs(self):
         """(indice_pairs int32[K,2,n_out], indice_pair_num int32[K]) -- spconv's pair-list view."""
@@ -126,7 +127,9 @@ class Rulebook:
         return self.nbr_t
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize):
+def rulebook_subm(indices, batch_size, spatial_shape, ksize, rank=None):
+    """Submanifold rulebook. `rank` = rank table of this site set (Rulebook.out_rank of the strided
+    conv that produced `indices`): lookups then need no hash table."""
     _need_gpu(indices, "indices")
     if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4:
         raise ValueError("indices must be int32 [N, 4] (batch, z, y, x)")
@@ -136,6 +139,13 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize):
     kvol = ks[0] * ks[1] * ks[2]
     nbr = torch.empty((kvol, n), dtype=torch.int32, device=indices.device)
     lib = L.lib()
+    if rank is not None:
+        with torch.cuda.device(indices.device):
+            rc = lib.vx_rulebook_subm_ranked(_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape),
+                                             L.i32x3(ks), _ptr(rank), _ptr(nbr), max(n, 1), _stream())
+        L.check(rc, "vx_rulebook_subm_ranked")
+        return Rulebook(nbr, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, spatial_shape, spatial_shape,
+                        indices)
     wsb = lib.vx_rulebook_workspace_bytes(n, int(batch_size), None)
     ws = _ws(wsb, indices.device)
     with torch.cuda.device(indices.device):
@@ -175,10 +185,13 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, tr
         out_idx = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
         nbr = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
         nbr_t = torch.empty((kvol, max(n, 1)), dtype=torch.int32, device=dev) if transpose else None
+        rank = torch.empty((max(lib.vx_rank_table_bytes(int(batch_size), osh), 8),), dtype=torch.uint8, device=dev)
         rc = lib.vx_rulebook_conv_emit(*args, n_out, _ptr(out_idx), _ptr(nbr), max(n_out, 1), _ptr(nbr_t),
-                                       max(n, 1), _ptr(ws), wsb, _stream())
+                                       max(n, 1), _ptr(rank), _ptr(ws), wsb, _stream())
         L.check(rc, "vx_rulebook_conv_emit")
-    return Rulebook(nbr, n, n_out, ks, st, pd, False, spatial_shape, list(osh), out_idx, nbr_t)
+    rb = Rulebook(nbr, n, n_out, ks, st, pd, False, spatial_shape, list(osh), out_idx, nbr_t)
+    rb.out_rank = rank if n and n_out else None
+    return rb
 
 
 def nbr_to_pairs(nbr):
