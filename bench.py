@@ -144,14 +144,19 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # "nccl" is RCCL on ROCm; VX_DIST_BACKEND=gloo only for rehearsing N>1 on a one-GPU box
+        dist.init_process_group(os.environ.get("VX_DIST_BACKEND", "nccl"))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
 
     if a.mode == "train":
         from vista_amd.train import bench_train

@@ -32,7 +32,13 @@ def allreduce_grads_flat(params, dist=None, world=1):
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
     if dist is not None and world > 1:
-        dist.all_reduce(flat)
+        if flat.is_cuda and dist.get_backend() != "nccl":
+            # CPU rehearsal backends (gloo) stage through host memory; RCCL reduces in place on the GPU
+            host = flat.cpu()
+            dist.all_reduce(host)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat)
         flat.div_(world)
         off = 0
         for g in grads:
@@ -42,8 +48,10 @@ def allreduce_grads_flat(params, dist=None, world=1):
     return flat.numel() * flat.element_size()
 
 
-def wrap_sync_bn(module, world):
-    if world > 1:
+def wrap_sync_bn(module, world, dist=None):
+    """SyncBatchNorm like the reference (train.py:301). Its collectives need the nccl (RCCL) backend
+    for GPU tensors; under any other backend (CPU rehearsals) the per-rank BatchNorm is kept."""
+    if world > 1 and dist is not None and dist.get_backend() == "nccl":
         return torch.nn.SyncBatchNorm.convert_sync_batchnorm(module)
     return module
 
@@ -69,7 +77,7 @@ def bench_train(a, dev, rank, world, dist):
     grid = grid_size(rg, vs).tolist()
     net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
                                        backbone_state_dict("SpMiddleResNetFHD")).to(dev).train()
-    net = wrap_sync_bn(net, world)
+    net = wrap_sync_bn(net, world, dist)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     frames = [torch.from_numpy(lidar_cloud(seed=rank * a.batch + b, sweeps=10)).to(dev) for b in range(a.batch)]
 
@@ -77,17 +85,22 @@ def bench_train(a, dev, rank, world, dist):
         mean, coords, _ = voxelize_batch(gen, frames)
         return train_step(net, opt, mean, coords, len(frames), grid, dist, world)
 
+    def barrier():
+        if dist is not None:
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
+
     for _ in range(a.warmup):
         step()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
