@@ -188,7 +188,7 @@ def main():
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16",
         "data": "synthetic",
-        "config": {"workload": f"{a.geometry} 10-sweep synthetic nuScenes-shaped frames, sparse_shape "
+        "config": {"workload": f"{a.geometry} {40 if a.geometry == "STRESS" else 10}-sweep synthetic nuScenes-shaped frames, sparse_shape "
                                f"{[grid[2] + 1, grid[1], grid[0]]}, batch {a.batch}/GPU, inference, "
                                "inputs resident in HBM (BASELINE.json configs[1])",
                    "frames_per_gpu": a.batch, "points_per_frame": int(np.mean([f.shape[0] for f in frames])),

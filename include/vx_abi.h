@@ -107,6 +107,12 @@ int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, int32_t batc
                                 const int32_t* shape, const int32_t* ksize, const void* d_rank,
                                 int32_t* d_nbr, int64_t nbr_ld, void* stream);
 
+/* Mask-sorted row order for the conv kernel (no counterpart in the reference: an MI355X scheduling
+ * aid). Inside windows of 16384 rows, rows are sorted by their "offsets used" bit mask so the 32-row
+ * MFMA groups of vx_spconv_fwd skip more (group, offset) slots. d_nbr_sorted[k][j] = d_nbr[k][d_perm[j]]. */
+int32_t vx_rulebook_sort_rows(const int32_t* d_nbr, int64_t nbr_ld, int32_t kvol, int64_t n_out,
+                              int32_t* d_nbr_sorted, int64_t sorted_ld, int32_t* d_perm, void* stream);
+
 /* pair-list view (spconv's indice_pairs): d_pairs int32[K][2][n_out] ((in,out) per offset, ordered
  * by output row, -1 padded), d_pair_num int32[K]. Wavefront-ballot compaction. */
 size_t vx_pairs_workspace_bytes(int32_t kvol, int64_t n_out);
@@ -123,12 +129,23 @@ int32_t vx_nbr_to_pairs(const int32_t* d_nbr, int64_t nbr_ld, int32_t kvol, int6
  * d_in   device [n_in][cin], d_out device [n_out][cout], d_residual device [n_out][cout] or NULL
  * d_weight device [cout][kvol][cin] (KRSC, the nn.Parameter layout), dtype = VX_F32 | VX_BF16 for
  * in/out/weight/residual; bias/scale/shift are always f32[cout] (or NULL).
+ * d_perm (optional): d_nbr is a mask-sorted table from vx_rulebook_sort_rows and table row j
+ * computes output row d_perm[j]; results are bitwise identical to the unsorted call.
+ * d_wpack (optional): see vx_spconv_pack_weight below.
  * ------------------------------------------------------------------------------------------- */
 int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
                       int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
                       int64_t n_out, const float* d_bias, const float* d_scale,
-                      const float* d_shift, const void* d_residual, int32_t flags, void* d_out,
-                      int32_t dtype, void* stream);
+                      const float* d_shift, const void* d_residual, int32_t flags,
+                      const int32_t* d_perm, const void* d_wpack, void* d_out, int32_t dtype,
+                      void* stream);
+
+/* Optional fp32 fast path: a copy of the weight packed in MFMA-fragment order. When d_wpack is
+ * given to vx_spconv_fwd (fp32, cin in {8,16,32,64,128}, cout <= 128) the barrier-free streaming-W
+ * kernel runs: same results to fp32 rounding of the same sums (identical summation order). */
+size_t vx_spconv_pack_weight_bytes(int32_t cin, int32_t cout, int32_t kvol);
+int32_t vx_spconv_pack_weight(const void* d_weight, int32_t cin, int32_t cout, int32_t kvol,
+                              void* d_wpack, void* stream);
 
 /* dgrad: din[i] = sum_k W[:,k,:]^T . dout[nbr_t[k][i]]  (input-stationary, atomic-free, same MFMA
  * kernels as forward). d_weight_t is the TRANSPOSED weight copy [cin][kvol][cout]

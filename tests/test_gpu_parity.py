@@ -424,3 +424,55 @@ def test_backbone_forward_bf16_vs_oracle(dev):
     assert out.dtype == torch.bfloat16 and tuple(out.shape) == ref.shape
     err = np.abs(out.float().cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err <= 2e-2, err
+
+
+def test_mask_sorted_rows_bitwise_identical(dev):
+    """vx_rulebook_sort_rows only re-groups rows into MFMA tiles: perm is a permutation that stays
+    inside 16384-row windows, the sorted table is the permuted table, and conv_fwd gives the same
+    bits with and without it."""
+    from vista_amd import ops
+    rng = np.random.default_rng(9)
+    shape = [11, 120, 120]
+    coords = random_sites(rng, 2, shape, 20000)
+    n = coords.shape[0]
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    nbr_s, perm = rb.sorted_table()
+    p = perm.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(p), np.arange(n))
+    assert np.all(p // 16384 == np.arange(n) // 16384)
+    nbr = rb.nbr.cpu().numpy()
+    np.testing.assert_array_equal(nbr_s.cpu().numpy(), nbr[:, p])
+    masks = ((nbr[:, p] >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+    for w0 in range(0, n, 16384):
+        assert np.all(np.diff(masks[w0:w0 + 16384]) >= 0)      # sorted by mask inside each window
+    for cin, cout, dt in [(64, 64, torch.float32), (128, 128, torch.float32), (32, 64, torch.bfloat16)]:
+        x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).to(dev).to(dt)
+        w = torch.from_numpy((rng.normal(size=(cout, 3, 3, 3, cin)) / 30).astype(np.float32)).to(dev).to(dt)
+        res = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).to(dev).to(dt)
+        a = ops.conv_fwd(x, w, rb, residual=res, relu=True, sort_rows=True)
+        b = ops.conv_fwd(x, w, rb, residual=res, relu=True, sort_rows=False)
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 128), (128, 32)])
+def test_conv_fwd_streaming_w_kernel(cin, cout, dev):
+    """fp32 streaming-W kernel (packed weights): same summation order as the LDS-staged kernel ->
+    bitwise equal to it, and within 1e-4 of the oracle."""
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape = [9, 60, 60]
+    coords = random_sites(rng, 2, shape, 5000)
+    n = coords.shape[0]
+    feat = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    nbr = so.rulebook_subm(coords, shape, 3)
+    ref = so.conv_fwd(feat, w, nbr, bias)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    x, wt, b = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev)
+    wp = ops.pack_weight(wt)
+    got = ops.conv_fwd(x, wt, rb, bias=b, relu=False, wpack=wp, sort_rows=True)
+    base = ops.conv_fwd(x, wt, rb, bias=b, relu=False)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert torch.equal(got, base)

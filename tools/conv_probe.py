@@ -9,6 +9,8 @@ from vista_amd.voxel import VoxelGenerator, voxelize_batch
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
+use_ws = len(sys.argv) > 2 and sys.argv[2] == "ws"
+sort_rows = len(sys.argv) > 3 and sys.argv[3] == "sort"
 dev = torch.device("cuda:0")
 rg, vs, T, mv = GEOMETRIES["FHD"]
 gen = VoxelGenerator(vs, rg, T, mv)
@@ -31,13 +33,14 @@ for name, cin, cout, rb in stages:
     x = torch.from_numpy(rng.normal(size=(rb.n_in, cin)).astype(np.float32)).to(dev).to(dt)
     w = torch.from_numpy((rng.normal(size=(cout, *rb.ksize, cin)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev).to(dt)
     pairs = int((rb.nbr >= 0).sum().item())
+    wp = ops.pack_weight(w) if use_ws else None
     for _ in range(2):
-        ops.conv_fwd(x, w, rb)
+        ops.conv_fwd(x, w, rb, wpack=wp, sort_rows=sort_rows)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        ops.conv_fwd(x, w, rb)
+        ops.conv_fwd(x, w, rb, wpack=wp, sort_rows=sort_rows)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * pairs * cin * cout

@@ -40,7 +40,11 @@ SIGNATURES = {
                                   c_size_t, c_void_p]),
     "vx_spconv_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p,
                                 c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
-                                c_void_p, c_int32, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "vx_spconv_pack_weight_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "vx_spconv_pack_weight": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "vx_rulebook_sort_rows": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int64, c_void_p,
+                                        c_void_p]),
     "vx_spconv_dgrad": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p,
                                   c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
     "vx_spconv_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),

@@ -34,6 +34,7 @@ struct ConvArgs {
   int relu;
   float* out;           // [n_out][cout]
   int dtype;            // VX_F32 | VX_BF16 (element type of in / w / residual / out)
+  const int* perm;      // optional: tile row j computes output row perm[j] (table is pre-permuted)
 };
 
 // bijective XCD-aware remap: consecutive tiles (which share gathered neighbours) run on one XCD
@@ -150,11 +151,12 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
     for (int i = 0; i < 16; ++i) {
       const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
       if (row >= a.n_out) continue;
+      const long long orow = a.perm ? a.perm[row] : row;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
-      if (a.residual) v += a.residual[row * a.cout + col];
+      if (a.residual) v += a.residual[orow * a.cout + col];
       if (a.relu) v = fmaxf(v, 0.0f);
-      a.out[row * a.cout + col] = v;
+      a.out[orow * a.cout + col] = v;
     }
   }
 }
@@ -364,11 +366,12 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
     for (int i = 0; i < 16; ++i) {
       const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
       if (row >= a.n_out) continue;
+      const long long orow = a.perm ? a.perm[row] : row;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
-      if (res) v += Elem<T>::load(res + row * a.cout + col);
+      if (res) v += Elem<T>::load(res + orow * a.cout + col);
       if (a.relu) v = fmaxf(v, 0.0f);
-      Elem<T>::store(out + row * a.cout + col, v);
+      Elem<T>::store(out + orow * a.cout + col, v);
     }
   }
 }
@@ -403,6 +406,175 @@ int32_t dispatch_w8(const ConvArgs& a, hipStream_t s) {
     case 64: return dispatch_w8_cout<T, 64>(a, s);
     case 128: return dispatch_w8_cout<T, 128>(a, s);
     default: return 1;  // not eligible
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Streaming-W kernel (fp32 only): one wave = one workgroup = 32 output rows, NO barriers.
+// W is read from a copy packed in MFMA-fragment order (vx_spconv_pack_weight): every B-fragment
+// load is one coalesced 1 KiB wave-instruction served by L2, prefetched one j-step ahead; the
+// gathered operand is prefetched one active chunk ahead as in spconv_w8. Because waves never wait
+// for each other, a wave skips exactly the chunks ITS 32 rows do not use -- this is what makes the
+// mask-sorted row order pay (useful MFMA rows 0.58 -> 0.76 at C=64). Only sensible where the MFMA
+// is slow relative to L2 bandwidth: fp32 (a bf16 wave would need 128 B/clk/CU of W from L2).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT_PAD>
+__global__ __launch_bounds__(64) void spconv_f32_ws(ConvArgs a, const f32x4* __restrict__ wp) {
+  constexpr int CK = 64;               // staged values per chunk
+  constexpr int NT = COUT_PAD / 32;
+  __shared__ int sIdx[kKSlots * 32];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * 32;
+  const int nchunks = (a.kvol * CIN + CK - 1) / CK;
+  const float* in = a.in;
+
+  unsigned wmask = 0;
+#pragma unroll
+  for (int i = 0; i < kKSlots / 2; ++i) {
+    const int ks = 2 * i + h;
+    int idx = -1;
+    if (ks < a.kvol && row0 + r < a.n_out) {
+      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
+      idx = a.nbr[(long long)krow * a.ld + row0 + r];
+    }
+    sIdx[ks * 32 + r] = idx;
+    const unsigned long long b = __ballot(idx >= 0);
+    if ((unsigned)b) wmask |= 1u << (2 * i);
+    if ((unsigned)(b >> 32)) wmask |= 1u << (2 * i + 1);
+  }
+  __syncthreads();  // single wave: orders the LDS writes above before the reads below
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  auto chunk_used = [&](int c) {
+    const int g0 = c * CK / CIN;
+    constexpr int span = (CK + CIN - 1) / CIN;
+    constexpr unsigned bits = (span >= 32) ? 0xffffffffu : ((1u << span) - 1u);
+    return ((wmask >> g0) & bits) != 0u;
+  };
+  auto next_chunk = [&](int c) {
+    ++c;
+    while (c < nchunks && !chunk_used(c)) ++c;
+    return c;
+  };
+  auto load_a = [&](int c, f32x4(&dst)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int P = c * CK + h * (CK / 2) + 4 * q;
+      const int g = P / CIN, ch = P % CIN;
+      const int idx = g < kKSlots ? sIdx[g * 32 + r] : -1;
+      const float* src = idx >= 0 ? in + (long long)idx * CIN + ch : vx_zero_row;
+      dst[q] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  // packed layout: [chunk][t][j][lane] quads
+  auto load_b = [&](int c, int j, f32x4(&dst)[NT]) {
+    const f32x4* p = wp + (((long long)c * NT) * 8 + j) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dst[t] = p[t * 8 * 64];
+  };
+
+  f32x4 a0[8], a1[8], b0[NT], b1[NT];
+  // process chunk c (A in `cur`, B(j=0) already in b0); prefetch chunk cn
+  auto run_chunk = [&](int c, int cn, const f32x4(&cur)[8], f32x4(&nxt)[8]) {
+    if (cn < nchunks) load_a(cn, nxt);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      load_b(c, j + 1, b1);
+      Elem<float>::template mma<NT>(cur[j], b0, acc);
+      if (j + 2 < 8) load_b(c, j + 2, b0);
+      else if (cn < nchunks) load_b(cn, 0, b0);
+      Elem<float>::template mma<NT>(cur[j + 1], b1, acc);
+    }
+  };
+
+  int c = next_chunk(-1);
+  if (c < nchunks) {
+    load_a(c, a0);
+    load_b(c, 0, b0);
+  }
+  while (c < nchunks) {
+    const int c1 = next_chunk(c);
+    run_chunk(c, c1, a0, a1);
+    if (c1 >= nchunks) break;
+    const int c2 = next_chunk(c1);
+    run_chunk(c1, c2, a1, a0);
+    c = c2;
+  }
+
+  const int col0 = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + r;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.0f;
+    const float sc = a.scale ? a.scale[col] : 1.0f;
+    const float sh = a.shift ? a.shift[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (row >= a.n_out) continue;
+      const long long orow = a.perm ? a.perm[row] : row;
+      float v = acc[t][i] + b;
+      if (a.scale || a.shift) v = v * sc + sh;
+      if (a.residual) v += a.residual[orow * a.cout + col];
+      if (a.relu) v = fmaxf(v, 0.0f);
+      a.out[orow * a.cout + col] = v;
+    }
+  }
+}
+
+// W[cout][kvol][cin] (KRSC) -> packed quads [chunk][t][j][lane], zero padded
+__global__ __launch_bounds__(256) void pack_weight_ws(const float* __restrict__ w, int cout, int kvol,
+                                                      int cin, int nt, int nchunks,
+                                                      f32x4* __restrict__ wp) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)nchunks * nt * 8 * 64;
+  if (e >= total) return;
+  const int lane = (int)(e & 63);
+  const int j = (int)((e >> 6) & 7);
+  const int t = (int)((e >> 9) % nt);
+  const int c = (int)((e >> 9) / nt);
+  const int col = t * 32 + (lane & 31);
+  const long long s0 = (long long)c * 64 + (lane >> 5) * 32 + 4 * j;  // staged position (k*cin + ci)
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (col < cout) {
+    const float* src = w + (long long)col * kvol * cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (s0 + i < (long long)kvol * cin) v[i] = src[s0 + i];
+  }
+  wp[e] = v;
+}
+
+template <int CIN, int COUT_PAD>
+int32_t launch_ws(const ConvArgs& a, const void* wp, hipStream_t stream) {
+  spconv_f32_ws<CIN, COUT_PAD><<<(unsigned)vx_cdiv(a.n_out, 32), 64, 0, stream>>>(a, (const f32x4*)wp);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+template <int CIN>
+int32_t dispatch_ws_cout(const ConvArgs& a, const void* wp, hipStream_t s) {
+  if (a.cout <= 32) return launch_ws<CIN, 32>(a, wp, s);
+  if (a.cout <= 64) return launch_ws<CIN, 64>(a, wp, s);
+  return launch_ws<CIN, 128>(a, wp, s);
+}
+
+int32_t dispatch_ws(const ConvArgs& a, const void* wp, hipStream_t s) {
+  switch (a.cin) {
+    case 8: return dispatch_ws_cout<8>(a, wp, s);
+    case 16: return dispatch_ws_cout<16>(a, wp, s);
+    case 32: return dispatch_ws_cout<32>(a, wp, s);
+    case 64: return dispatch_ws_cout<64>(a, wp, s);
+    case 128: return dispatch_ws_cout<128>(a, wp, s);
+    default: return 1;
   }
 }
 
@@ -451,7 +623,8 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
                                  int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
                                  int64_t n_out, const float* d_bias, const float* d_scale,
                                  const float* d_shift, const void* d_residual, int32_t flags,
-                                 void* d_out, int32_t dtype, void* stream) {
+                                 const int32_t* d_perm, const void* d_wpack, void* d_out,
+                                 int32_t dtype, void* stream) {
   VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "spconv_fwd: dtype must be VX_F32 or VX_BF16");
   VX_REQUIRE(cin >= 1 && cin <= 128 && cout >= 1 && kvol >= 1 && kvol <= 125,
              "spconv_fwd: need 1 <= cin <= 128, cout >= 1, 1 <= kvol <= 125");
@@ -479,7 +652,30 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
   a.relu = (flags & VX_EPI_RELU) ? 1 : 0;
   a.out = (float*)d_out;
   a.dtype = dtype;
+  a.perm = d_perm;
+  if (d_wpack && dtype == VX_F32 && cout <= 128 && kvol <= kKSlots &&
+      (reinterpret_cast<uintptr_t>(d_in) & 15) == 0) {
+    const int32_t rc = dispatch_ws(a, d_wpack, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   return dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" size_t vx_spconv_pack_weight_bytes(int32_t cin, int32_t cout, int32_t kvol) {
+  const size_t nchunks = ((size_t)kvol * cin + 63) / 64, nt = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+  return nchunks * nt * 8 * 64 * 16;
+}
+
+extern "C" int32_t vx_spconv_pack_weight(const void* d_weight, int32_t cin, int32_t cout,
+                                         int32_t kvol, void* d_wpack, void* stream) {
+  VX_REQUIRE(d_weight && d_wpack && cin >= 1 && cout >= 1 && cout <= 128 && kvol >= 1,
+             "spconv_pack_weight: need cout <= 128 and non-null pointers");
+  const int nchunks = (kvol * cin + 63) / 64, nt = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+  const long long total = (long long)nchunks * nt * 8 * 64;
+  pack_weight_ws<<<(unsigned)vx_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(
+      (const float*)d_weight, cout, kvol, cin, nt, nchunks, (f32x4*)d_wpack);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
 }
 
 extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t cout,
@@ -509,5 +705,6 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.relu = 0;
   a.out = (float*)d_din;
   a.dtype = dtype;
+  a.perm = nullptr;
   return dispatch(a, (hipStream_t)stream);
 }

@@ -207,6 +207,64 @@ __global__ void pairs_num(const int* __restrict__ woff, const int* __restrict__ 
   pair_num[k] = woff[last] + wcnt[last] - woff[(long long)k * nw];
 }
 
+
+// ---- mask-sorted row order --------------------------------------------------------------------
+// The conv kernel skips a kernel offset for a 32-row MFMA group only when no row of the group uses
+// it. Rows are therefore re-grouped: inside windows of 16384 consecutive rows (locality for the
+// gathers is kept) rows are sorted by their 27-bit "offsets used" mask, so groups hold rows with
+// equal or similar masks and far fewer (group, offset) slots carry absent neighbours
+// (measured on FHD rulebooks: useful MFMA rows 0.58 -> 0.76 at C=64, 0.46 -> 0.79 at C=32).
+// One 1024-thread workgroup per window: masks from the table, bitonic sort of 64-bit
+// (mask << 32 | local row) keys in LDS (128 KB), then the table is permuted once per rulebook.
+constexpr int kSortTile = 16384;
+constexpr int kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void mask_sort_tiles(const int* __restrict__ nbr,
+                                                                long long ld, int kvol,
+                                                                long long n, int* __restrict__ perm) {
+  extern __shared__ unsigned long long skey[];  // [kSortTile]
+  const long long base = (long long)blockIdx.x * kSortTile;
+  for (int j = threadIdx.x; j < kSortTile; j += kSortThreads) {
+    const long long o = base + j;
+    unsigned long long key = ~0ull;
+    if (o < n) {
+      unsigned m = 0;
+      for (int k = 0; k < kvol && k < 32; ++k) m |= (nbr[(long long)k * ld + o] >= 0 ? 1u : 0u) << k;
+      key = ((unsigned long long)m << 32) | (unsigned)j;
+    }
+    skey[j] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= kSortTile; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < kSortTile / 2; t += kSortThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+        const int p = i | j;
+        const unsigned long long a = skey[i], b = skey[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          skey[i] = b;
+          skey[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < kSortTile; j += kSortThreads) {
+    const long long o = base + j;
+    if (o < n) perm[o] = (int)(base + (long long)(unsigned)(skey[j] & 0xffffffffull));
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void permute_table(const int* __restrict__ nbr, long long ld,
+                                                          long long n, const int* __restrict__ perm,
+                                                          int* __restrict__ out, long long ld_out) {
+  const long long j = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j >= n) return;
+  out[(long long)k * ld_out + j] = nbr[(long long)k * ld + perm[j]];
+}
+
 int fill_geom(ConvGeom* g, const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
               const int32_t* pad, bool subm) {
   g->kvol = 1;
@@ -400,6 +458,26 @@ extern "C" int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, i
   VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm_ranked: bad table pointer / stride");
   dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)g.kvol);
   subm_nbr_ranked<<<grid, kThreads, 0, stream>>>(d_coords, n, g, (const uint2*)d_rank, d_nbr, nbr_ld);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" int32_t vx_rulebook_sort_rows(const int32_t* d_nbr, int64_t nbr_ld, int32_t kvol,
+                                         int64_t n_out, int32_t* d_nbr_sorted, int64_t sorted_ld,
+                                         int32_t* d_perm, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(kvol >= 1 && kvol <= 125 && n_out >= 0, "rulebook_sort_rows: bad arguments");
+  if (n_out == 0) return VX_OK;
+  VX_REQUIRE(d_nbr && d_nbr_sorted && d_perm && nbr_ld >= n_out && sorted_ld >= n_out,
+             "rulebook_sort_rows: null pointer / stride");
+  const size_t lds = (size_t)kSortTile * sizeof(unsigned long long);
+  VX_HIP(hipFuncSetAttribute((const void*)mask_sort_tiles,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  mask_sort_tiles<<<(unsigned)vx_cdiv(n_out, kSortTile), kSortThreads, lds, stream>>>(
+      d_nbr, nbr_ld, kvol, n_out, d_perm);
+  VX_LAUNCH_CHECK();
+  dim3 grid((unsigned)vx_cdiv(n_out, kThreads), (unsigned)kvol);
+  permute_table<<<grid, kThreads, 0, stream>>>(d_nbr, nbr_ld, n_out, d_perm, d_nbr_sorted, sorted_ld);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }

@@ -23,7 +23,7 @@ def _fold_bn(bn, dev):
 
 
 class _Step:
-    __slots__ = ("kind", "w", "w32", "bias", "scale", "shift", "relu", "key", "ksize", "stride", "padding", "residual")
+    __slots__ = ("kind", "w", "w32", "wpack", "bias", "scale", "shift", "relu", "key", "ksize", "stride", "padding", "residual")
 
 
 def _compile_sequential(seq, dev, dtype):
@@ -37,6 +37,7 @@ def _compile_sequential(seq, dev, dtype):
         s.kind = "subm" if conv.subm else "conv"
         s.w = conv.weight.detach().to(dev, dtype).contiguous()
         s.w32 = conv.weight.detach().to(dev, torch.float32).contiguous() if conv.in_channels % 8 else None
+        s.wpack = None   # ops.pack_weight(s.w) would select the streaming-W kernel (slower end to end)
         s.bias = conv.bias.detach().float().to(dev).contiguous() if conv.bias is not None else None
         s.scale, s.shift = _fold_bn(bn, dev) if bn is not None else (None, None)
         s.relu, s.key, s.residual = relu, conv.indice_key, residual
@@ -96,7 +97,7 @@ def _run(steps, st, geom_only=False):
                 # first layer: the voxelizer's fp32 means (Cin=5) run through the fp32 kernel
                 w = s.w32
             st.feat = ops.conv_fwd(st.feat, w, rb, bias=s.bias, scale=s.scale, shift=s.shift,
-                                   residual=res, relu=s.relu)
+                                   residual=res, relu=s.relu, wpack=s.wpack if w is s.w else None)
             if st.feat.dtype != s.w.dtype:
                 st.feat = st.feat.to(s.w.dtype)
         if s.kind == "conv":

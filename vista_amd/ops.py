@@ -99,12 +99,25 @@ class Rulebook:
         self.kvol = ksize[0] * ksize[1] * ksize[2]
         self._pairs = None
         self.out_rank = None  # rank table of the output site set (strided convs): see rulebook_subm
+        self._sorted = None
 
     def pairs(self):
         """(indice_pairs int32[K,2,n_out], indice_pair_num int32[K]) -- spconv's pair-list view."""
         if self._pairs is None:
             self._pairs = nbr_to_pairs(self.nbr)
         return self._pairs
+
+    def sorted_table(self):
+        """(nbr_sorted int32[K,n_out], perm int32[n_out]): mask-sorted row order for conv_fwd."""
+        if self._sorted is None:
+            nbr_s = torch.empty_like(self.nbr)
+            perm = torch.empty((max(self.n_out, 1),), dtype=torch.int32, device=self.nbr.device)
+            with torch.cuda.device(self.nbr.device):
+                rc = L.lib().vx_rulebook_sort_rows(_ptr(self.nbr), max(self.n_out, 1), self.kvol, self.n_out,
+                                                   _ptr(nbr_s), max(self.n_out, 1), _ptr(perm), _stream())
+            L.check(rc, "vx_rulebook_sort_rows")
+            self._sorted = (nbr_s, perm)
+        return self._sorted
 
     @property
     def indice_pairs(self):
@@ -212,9 +225,29 @@ def nbr_to_pairs(nbr):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
-def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False):
+def pack_weight(weight):
+    """fp32 KRSC weight -> MFMA-fragment-ordered copy for the streaming-W kernel (conv_fwd(wpack=...))."""
+    _need_gpu(weight, "weight")
+    if weight.dtype != torch.float32:
+        raise ValueError("pack_weight: fp32 weights only")
+    weight = weight.contiguous()
+    cout, cin = weight.shape[0], weight.shape[-1]
+    kvol = weight.numel() // (cout * cin)
+    lib = L.lib()
+    out = torch.empty((lib.vx_spconv_pack_weight_bytes(cin, cout, kvol),), dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.vx_spconv_pack_weight(_ptr(weight), cin, cout, kvol, _ptr(out), _stream())
+    L.check(rc, "vx_spconv_pack_weight")
+    return out
+
+
+def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False,
+             sort_rows=False, wpack=None):
     """features [n_in,Cin], weight [Cout,kz,ky,kx,Cin] (KRSC) -> [n_out,Cout]; fused epilogue
-    relu?((acc + bias) * scale + shift + residual)."""
+    relu?((acc + bias) * scale + shift + residual). sort_rows: run on the rulebook's mask-sorted
+    row order (same bits out); wpack: packed weight copy -> barrier-free streaming-W kernel (fp32).
+    Both are OFF by default: measured on MI355X they only pay together, on the
+    sparse strided layers, and the sort costs what they save."""
     _need_gpu(features, "features")
     if features.dtype not in _DT:
         raise ValueError(f"unsupported feature dtype {features.dtype}")
@@ -235,16 +268,19 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
         residual = residual.contiguous()
         if residual.shape != out.shape or residual.dtype != out.dtype:
             raise ValueError("residual must match the output shape and dtype")
+    nbr, perm = rb.nbr, None
+    if sort_rows and rb.n_out >= 4096 and rb.kvol > 1:
+        nbr, perm = rb.sorted_table()
     rec = None
     if TIMING is not None:
         rec = dict(cin=cin, cout=cout, kvol=rb.kvol, rb=rb, ev0=torch.cuda.Event(enable_timing=True),
                    ev1=torch.cuda.Event(enable_timing=True))
         rec["ev0"].record()
     with torch.cuda.device(features.device):
-        rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(rb.nbr),
+        rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(nbr),
                                    max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
-                                   _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(out),
-                                   _DT[features.dtype], _stream())
+                                   _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(perm), _ptr(wpack),
+                                   _ptr(out), _DT[features.dtype], _stream())
     if rec is not None:
         rec["ev1"].record()
         TIMING.append(rec)
