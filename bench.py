@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--geometry", default="FHD", choices=["FHD", "VISTA", "STRESS"])
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
+    ap.add_argument("--backbone", default="SpMiddleResNetFHD", choices=["SpMiddleResNetFHD", "MultiViewBackbone"],
+                    help="MultiViewBackbone needs --geometry VISTA (multiview.py:88-106)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     return ap.parse_args()
@@ -96,7 +98,7 @@ def timed_infer(gen, engine, frames, grid, steps, warmup, barrier):
 def dominant_kernel_roofline(timing, dtype):
     """HIP-event time of every launch of the dominant conv kernel (Cin=Cout=128) in the timed region
     vs its algorithmic FLOPs 2*pairs*Cin*Cout."""
-    sel = [t for t in timing if t["cin"] == 128 and t["cout"] == 128 and t["kvol"] == 27]
+    sel = [t for t in timing if t["op"] == "conv" and t["cin"] == 128 and t["cout"] == 128 and t["kvol"] == 27]
     if not sel:
         return None
     ms = np.array([t["ev0"].elapsed_time(t["ev1"]) for t in sel])
@@ -124,6 +126,50 @@ def dominant_kernel_roofline(timing, dtype):
     return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
             "traffic": pmc_traffic("bf16"), "kernel": "spconv_w8<bf16,128,128> (SubMConv3d 128->128, k=3)",
             "bytes_per_launch": float(nbytes.mean()), **common}
+
+
+def phase_report(timing, steps, batch):
+    """Per-phase time and achieved algorithmic rate (formulas of BASELINE.md section 2), from HIP events
+    around every C-ABI call in the timed region. ms are per frame."""
+    cache = {}
+
+    def npairs(nbr):
+        if id(nbr) not in cache:
+            cache[id(nbr)] = int((nbr >= 0).sum().item())
+        return cache[id(nbr)]
+
+    acc = {}
+    for t in timing:
+        ms = t["ev0"].elapsed_time(t["ev1"])
+        op = t["op"]
+        nbytes = flops = 0.0
+        if op == "voxelize":
+            nbytes = t["n_points"] * t["n_feat"] * 4 + t["n_points"] * 8 + t.get("n_voxels", 0) * (16 + 4 + t["n_feat"] * 4)
+        elif op == "rulebook_subm":
+            nbytes = t["n"] * 16 + t["kvol"] * t["n"] * 8 + npairs(t["nbr"]) * 8
+        elif op == "rulebook_conv":
+            nbytes = t["n"] * 16 + t["kvol"] * t["n"] * 8 + t.get("n_out", 0) * 16 + npairs(t["nbr"]) * 8
+        elif op == "conv":
+            p_ = npairs(t["rb"].nbr)
+            flops = 2.0 * p_ * t["cin"] * t["cout"]
+            s_ = t["esize"]
+            nbytes = p_ * t["cin"] * s_ + t["rb"].n_out * t["cout"] * s_ + t["kvol"] * t["cin"] * t["cout"] * s_ + p_ * 8
+            op = "conv_C>=64" if min(t["cin"], t["cout"]) >= 64 else "conv_C<64"
+        elif op == "dense":
+            nbytes = t["numel"] * t["esize"] + 2 * t["n"] * t["c"] * t["esize"]
+        a_ = acc.setdefault(op, [0.0, 0.0, 0.0, 0])
+        a_[0] += ms
+        a_[1] += nbytes
+        a_[2] += flops
+        a_[3] += 1
+    out = {}
+    for op, (ms, nbytes, flops, calls) in acc.items():
+        out[op] = {"ms_per_frame": ms / (steps * batch), "calls_per_step": calls / steps,
+                   "algorithmic_GB_per_s": nbytes / (ms * 1e-3) / 1e9 if ms else None,
+                   "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if ms else None}
+        if flops:
+            out[op]["TFLOP_per_s"] = flops / (ms * 1e-3) / 1e12
+    return out
 
 
 def pmc_traffic(dtype):
@@ -171,8 +217,8 @@ def main():
     gen = VoxelGenerator(vs, rg, T, mv)
     grid = grid_size(rg, vs).tolist()
     dtype = torch.float32 if a.dtype == "fp32" else torch.bfloat16
-    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
-                                       backbone_state_dict("SpMiddleResNetFHD")).to(dev).eval()
+    net = models.load_numpy_state_dict(getattr(models, a.backbone)(num_input_features=5),
+                                       backbone_state_dict(a.backbone)).to(dev).eval()
     engine = FusedBackbone(net, dtype=dtype)
     frames = make_frames(a.geometry, a.batch, rank, dev)
 
@@ -182,13 +228,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_frames = world * a.batch * a.steps
+    sweeps = 40 if a.geometry == "STRESS" else 10
     res = {
-        "metric": "backbone frames/sec (voxelize + mean VFE + SpMiddleResNetFHD forward)",
+        "metric": f"backbone frames/sec (voxelize + mean VFE + {a.backbone} forward)",
         "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16",
         "data": "synthetic",
-        "config": {"workload": f"{a.geometry} {40 if a.geometry == "STRESS" else 10}-sweep synthetic nuScenes-shaped frames, sparse_shape "
+        "config": {"workload": f"{a.geometry} {sweeps}-sweep synthetic nuScenes-shaped frames, sparse_shape "
                                f"{[grid[2] + 1, grid[1], grid[0]]}, batch {a.batch}/GPU, inference, "
                                "inputs resident in HBM (BASELINE.json configs[1])",
                    "frames_per_gpu": a.batch, "points_per_frame": int(np.mean([f.shape[0] for f in frames])),
@@ -196,6 +243,7 @@ def main():
     }
     if rank == 0:
         res["roofline"] = dominant_kernel_roofline(timing, a.dtype)
+        res["phases"] = phase_report(timing, a.steps, a.batch)
         if world == 1 and not a.no_variants:
             # batch-1 latency variant of the same workload (not part of `value`)
             dt1, _, _ = timed_infer(gen, engine, frames[:1], grid, max(3, a.steps), 2, barrier)

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 }
 
 
-constexpr int kKSlots = 32;  // index-table rows kept in LDS (kvol <= 32)
+constexpr int kKSlots = 28;  // index-table rows kept in LDS (kvol <= 28)
 
 // ------------------------------------------------------------------------------------------------
 // 8-wave kernel (hot path), fp32 and bf16.
@@ -183,7 +183,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kW8Threads = 512;
 constexpr int kW8Rows = 256;
 constexpr int kRowBytes = 256;          // staged bytes per row per chunk
-constexpr int kRowPad = kRowBytes + 16; // LDS row pitch
 
 template <typename T>
 struct Elem;
@@ -218,8 +217,226 @@ struct Elem<__bf16> {
   static __device__ __forceinline__ void store(__bf16* p, float v) { *p = (__bf16)v; }
 };
 
+#ifdef VX_STAMP  // diagnostic build only (tools/stamp_probe.py): where does a pipeline step spend its cycles
+__device__ unsigned long long vx_dbg[8];
+#define VX_STAMP_T(x)                                                                  \
+  unsigned long long x;                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");            \
+  __builtin_amdgcn_sched_barrier(0)
+#define VX_STAMP_ACC(i, v) stamp_sum[i] += (v)
+#define VX_STAMP_DECL unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}
+#define VX_STAMP_FLUSH                                                                 \
+  if (lane == 0)                                                                       \
+    for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&vx_dbg[i_], stamp_sum[i_])
+extern "C" int32_t vx_debug_read(unsigned long long* h8) {
+  if (hipMemcpyFromSymbol(h8, HIP_SYMBOL(vx_dbg), 64) != hipSuccess) return -1;
+  unsigned long long z[8] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(vx_dbg), z, 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define VX_STAMP_T(x)
+#define VX_STAMP_ACC(i, v)
+#define VX_STAMP_DECL
+#define VX_STAMP_FLUSH
+#endif
+
 template <typename T, int CIN, int COUT_PAD>
 __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
+  constexpr int VPQ = Elem<T>::VPQ;
+  constexpr int CK = kRowBytes / (int)sizeof(T);      // staged values per chunk (64 / 128)
+  constexpr int QPR = kRowBytes / 16;                 // 16-byte pieces per staged row (16)
+  constexpr int NT = COUT_PAD / 32;
+  constexpr int W_LD = (COUT_PAD * QPR + kW8Threads - 1) / kW8Threads;
+  constexpr int NW = kW8Threads / 64;
+  static_assert(CIN % VPQ == 0, "a quad must not straddle two neighbour rows");
+  // LDS: W chunk x2 | gathered tile per wave | neighbour indices per wave | masks
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* sA = smem_raw + 2 * COUT_PAD * kRowBytes + wave * 32 * kRowBytes;
+  int* sIdx = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowBytes + NW * 32 * kRowBytes) +
+              wave * kKSlots * 32;
+  int* sMask = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowBytes + NW * 32 * kRowBytes) +
+               NW * kKSlots * 32;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wgt = reinterpret_cast<const T*>(a.w);
+  const T* zero = reinterpret_cast<const T*>(vx_zero_row);
+
+  const int r = lane & 31, h = lane >> 5;
+  const long long tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long long row0 = tile * kW8Rows + wave * 32;
+  const int col0 = blockIdx.y * COUT_PAD;
+  const int nchunks = (a.kvol * CIN + CK - 1) / CK;
+
+  unsigned wmask = 0;
+#pragma unroll
+  for (int i = 0; i < kKSlots / 2; ++i) {
+    const int ks = 2 * i + h;
+    int idx = -1;
+    if (ks < a.kvol && row0 + r < a.n_out) {
+      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
+      idx = a.nbr[(long long)krow * a.ld + row0 + r];
+    }
+    sIdx[ks * 32 + r] = idx;
+    const unsigned long long b = __ballot(idx >= 0);
+    if ((unsigned)b) wmask |= 1u << (2 * i);
+    if ((unsigned)(b >> 32)) wmask |= 1u << (2 * i + 1);
+  }
+  if (lane == 0) sMask[wave] = (int)wmask;
+  __syncthreads();
+  unsigned gmask = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) gmask |= (unsigned)sMask[i];
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  // kernel offsets touched by chunk c: [c*CK/CIN, (c*CK+CK-1)/CIN]
+  auto chunk_used = [&](unsigned m, int c) {
+    const int g0 = c * CK / CIN;
+    constexpr int span = (CK + CIN - 1) / CIN;
+    constexpr unsigned bits = (span >= 32) ? 0xffffffffu : ((1u << span) - 1u);
+    return ((m >> g0) & bits) != 0u;
+  };
+  auto next_chunk = [&](int c) {
+    ++c;
+    while (c < nchunks && !chunk_used(gmask, c)) ++c;
+    return c;
+  };
+
+  f32x4 ra[8], rw[W_LD];
+  VX_STAMP_DECL;
+
+  // Gather: wave-instruction t covers tile rows 4t..4t+3, 16 lanes per row reading the row's 256
+  // staged bytes of this chunk as whole 128-byte lines (8 distinct lines per instruction instead
+  // of 64 for fragment-shaped loads: the texture-addresser was the bottleneck of that form).
+  const int arow = lane >> 4, ap = lane & 15;
+  auto load_a = [&](int c) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = 4 * t + arow;
+      const int P = c * CK + VPQ * ap;                 // staged value position of this piece
+      const int g = P / CIN, ch = P % CIN;
+      const int idx = g < kKSlots ? sIdx[g * 32 + row] : -1;   // slots >= kvol hold -1
+      const T* src = idx >= 0 ? in + (long long)idx * CIN + ch : zero;
+      ra[t] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  // LDS images are unpadded 256-byte rows with the 16-byte piece index XOR-ed by (row & 15):
+  // fragment reads (ds_read_b128, one piece per lane, 16 different rows per lane group) then hit
+  // 16 different 16-byte bank groups -> conflict-free without padding.
+  auto store_a = [&]() {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = 4 * t + arow;
+      *reinterpret_cast<f32x4*>(sA + row * kRowBytes + ((ap ^ (row & 15)) << 4)) = ra[t];
+    }
+  };
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kW8Threads + (int)threadIdx.x;
+      const int oc = e / QPR, q = e % QPR;
+      const int P = c * CK + VPQ * q;
+      const int g = P / CIN, ch = P % CIN;
+      const int goc = col0 + oc;
+      const bool ok = goc < a.cout && g < a.kvol && oc < COUT_PAD;
+      const T* src = ok ? wgt + ((long long)goc * a.kvol + g) * CIN + ch : zero;
+      rw[t] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_w = [&](int buf) {
+    char* sW = smem_raw + buf * COUT_PAD * kRowBytes;
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kW8Threads + (int)threadIdx.x;
+      const int oc = e / QPR, q = e % QPR;
+      if (oc < COUT_PAD) *reinterpret_cast<f32x4*>(sW + oc * kRowBytes + ((q ^ (oc & 15)) << 4)) = rw[t];
+    }
+  };
+  auto mfma_chunk = [&](int buf) {
+    const char* pb = smem_raw + buf * COUT_PAD * kRowBytes + r * kRowBytes;
+    const char* pa = sA + r * kRowBytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int off = ((h * 8 + j) ^ (r & 15)) << 4;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(pa + off);
+      f32x4 bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * kRowBytes + off);
+      Elem<T>::template mma<NT>(av, bv, acc);
+    }
+  };
+
+  int c = next_chunk(-1);
+  int buf = 0;
+  if (c < nchunks) {
+    load_w(c);
+    if (chunk_used(wmask, c)) {
+      load_a(c);
+      store_a();
+    }
+    store_w(0);
+  }
+  __syncthreads();
+  while (c < nchunks) {
+    // chunk c is staged (sA, sW[buf]); prefetch chunk cn into registers while its MFMAs run
+    const int cn = next_chunk(c);
+    const bool more = cn < nchunks;
+    const bool more_a = more && chunk_used(wmask, cn);
+    VX_STAMP_T(t1);
+    if (more) load_w(cn);
+    if (more_a) load_a(cn);
+    VX_STAMP_T(t2);
+    if (chunk_used(wmask, c)) mfma_chunk(buf);
+    VX_STAMP_T(t3);
+    if (more_a) store_a();
+    if (more) store_w(buf ^ 1);
+    VX_STAMP_T(t4);
+    __syncthreads();
+    VX_STAMP_T(t5);
+    VX_STAMP_ACC(1, t2 - t1); VX_STAMP_ACC(2, t3 - t2); VX_STAMP_ACC(3, t4 - t3);
+    VX_STAMP_ACC(4, t5 - t4); VX_STAMP_ACC(5, 1);
+    buf ^= 1;
+    c = cn;
+  }
+
+  VX_STAMP_FLUSH;
+  // ---- epilogue: bias, per-channel affine (folded BatchNorm), residual, ReLU ---------------------
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.residual);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + r;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.0f;
+    const float sc = a.scale ? a.scale[col] : 1.0f;
+    const float sh = a.shift ? a.shift[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (row >= a.n_out) continue;
+      const long long orow = a.perm ? a.perm[row] : row;
+      float v = acc[t][i] + b;
+      if (a.scale || a.shift) v = v * sc + sh;
+      if (res) v += Elem<T>::load(res + orow * a.cout + col);
+      if (a.relu) v = fmaxf(v, 0.0f);
+      Elem<T>::store(out + orow * a.cout + col, v);
+    }
+  }
+}
+
+// Direct-gather variant (small C): the gathered operand goes straight into VGPRs in fragment
+// layout (no LDS round trip); W rows are padded to 272 bytes. Faster than the LDS-staged gather
+// when a chunk holds few MFMAs (C <= 32), slower at C >= 64 where its 64-lines-per-instruction
+// loads saturate the texture addresser (measured with in-kernel stamps).
+constexpr int kRowPadD = kRowBytes + 16;
+
+template <typename T, int CIN, int COUT_PAD>
+__global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
   constexpr int VPQ = Elem<T>::VPQ;
   constexpr int CK = kRowBytes / (int)sizeof(T);      // staged values per chunk (64 / 128)
   constexpr int QPR = kRowBytes / 16;                 // quads per W row (16)
@@ -229,8 +446,8 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
   static_assert(CIN % VPQ == 0, "a quad must not straddle two neighbour rows");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int* sIdx = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPad) + wave * kKSlots * 32;
-  int* sMask = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPad) + NW * kKSlots * 32;
+  int* sIdx = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPadD) + wave * kKSlots * 32;
+  int* sMask = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPadD) + NW * kKSlots * 32;
   const T* in = reinterpret_cast<const T*>(a.in);
   const T* wgt = reinterpret_cast<const T*>(a.w);
   const T* zero = reinterpret_cast<const T*>(vx_zero_row);
@@ -306,21 +523,21 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
     }
   };
   auto store_w = [&](int buf) {
-    char* sW = smem_raw + buf * COUT_PAD * kRowPad;
+    char* sW = smem_raw + buf * COUT_PAD * kRowPadD;
 #pragma unroll
     for (int t = 0; t < W_LD; ++t) {
       const int e = t * kW8Threads + (int)threadIdx.x;
       const int oc = e / QPR, q = e % QPR;
-      if (oc < COUT_PAD) *reinterpret_cast<f32x4*>(sW + oc * kRowPad + q * 16) = rw[t];
+      if (oc < COUT_PAD) *reinterpret_cast<f32x4*>(sW + oc * kRowPadD + q * 16) = rw[t];
     }
   };
   auto mfma_chunk = [&](int buf, const f32x4(&ra)[8]) {
-    const char* pb = smem_raw + buf * COUT_PAD * kRowPad + r * kRowPad + h * (kRowBytes / 2);
+    const char* pb = smem_raw + buf * COUT_PAD * kRowPadD + r * kRowPadD + h * (kRowBytes / 2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       f32x4 bv[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * kRowPad + 16 * j);
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 32 * kRowPadD + 16 * j);
       Elem<T>::template mma<NT>(ra[j], bv, acc);
     }
   };
@@ -378,10 +595,15 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
 
 template <typename T, int CIN, int COUT_PAD>
 int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
-  constexpr size_t lds = (size_t)2 * COUT_PAD * kRowPad +
-                         (size_t)(kW8Threads / 64) * kKSlots * 32 * sizeof(int) + 64;
+  // LDS-staged gather where a chunk carries enough MFMA work to hide its LDS round trip
+  constexpr bool kLdsGather = sizeof(T) == 4 ? (CIN >= 64) : (CIN >= 128);
+  constexpr size_t lds_l = (size_t)2 * COUT_PAD * kRowBytes + (size_t)(kW8Threads / 64) * 32 * kRowBytes +
+                           (size_t)(kW8Threads / 64) * kKSlots * 32 * sizeof(int) + 64;
+  constexpr size_t lds_d = (size_t)2 * COUT_PAD * kRowPadD +
+                           (size_t)(kW8Threads / 64) * kKSlots * 32 * sizeof(int) + 64;
+  constexpr size_t lds = kLdsGather ? lds_l : lds_d;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = spconv_w8<T, CIN, COUT_PAD>;
+  auto kern = kLdsGather ? spconv_w8<T, CIN, COUT_PAD> : spconv_w8d<T, CIN, COUT_PAD>;
   VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
   dim3 grid((unsigned)vx_cdiv(a.n_out, kW8Rows), (unsigned)vx_cdiv(a.cout, COUT_PAD));

@@ -35,6 +35,27 @@ _DT = {torch.float32: L.VX_F32, torch.bfloat16: L.VX_BF16}
 TIMING = None
 
 
+class _Timed:
+    """with _Timed("op", **meta) as rec: ... -- records a HIP-event pair on the current stream."""
+
+    def __init__(self, op, **meta):
+        self.rec = None
+        if TIMING is not None:
+            self.rec = dict(op=op, ev0=torch.cuda.Event(enable_timing=True), ev1=torch.cuda.Event(enable_timing=True),
+                            **meta)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec["ev0"].record()
+        return self.rec
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.rec["ev1"].record()
+            TIMING.append(self.rec)
+        return False
+
+
 def triple(v):
     if isinstance(v, (int, np.integer)):
         return [int(v)] * 3
@@ -71,13 +92,15 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, batch_idx=0,
     lib = L.lib()
     wsb = lib.vx_voxelize_workspace_bytes(n)
     ws = _ws(wsb, dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _Timed("voxelize", n_points=n, n_feat=f) as rec:
         rc = lib.vx_voxelize_hard(_ptr(points), n, f, vs.ctypes.data_as(L.c_f32p), rg.ctypes.data_as(L.c_f32p),
                                   int(max_points), int(max_voxels), int(batch_idx), _ptr(coords), _ptr(nump),
                                   _ptr(voxels), _ptr(mean), cap, _ptr(d_m), ctypes.byref(h_m), _ptr(ws), wsb,
                                   _stream())
     L.check(rc, "vx_voxelize_hard")
     m = int(h_m.value)
+    if rec is not None:
+        rec["n_voxels"] = m
     return dict(coords=coords[:m], num_points=nump[:m],
                 voxels=voxels[:m] if voxels is not None else None,
                 mean=mean[:m] if mean is not None else None, num_voxels=m)
@@ -153,7 +176,7 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize, rank=None):
     nbr = torch.empty((kvol, n), dtype=torch.int32, device=indices.device)
     lib = L.lib()
     if rank is not None:
-        with torch.cuda.device(indices.device):
+        with torch.cuda.device(indices.device), _Timed("rulebook_subm", n=n, kvol=kvol, nbr=nbr):
             rc = lib.vx_rulebook_subm_ranked(_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape),
                                              L.i32x3(ks), _ptr(rank), _ptr(nbr), max(n, 1), _stream())
         L.check(rc, "vx_rulebook_subm_ranked")
@@ -161,7 +184,7 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize, rank=None):
                         indices)
     wsb = lib.vx_rulebook_workspace_bytes(n, int(batch_size), None)
     ws = _ws(wsb, indices.device)
-    with torch.cuda.device(indices.device):
+    with torch.cuda.device(indices.device), _Timed("rulebook_subm", n=n, kvol=kvol, nbr=nbr):
         rc = lib.vx_rulebook_subm(_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape), L.i32x3(ks),
                                   _ptr(nbr), max(n, 1), _ptr(ws), wsb, _stream())
     L.check(rc, "vx_rulebook_subm")
@@ -191,7 +214,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, tr
     ws = _ws(wsb, dev)
     h_n = ctypes.c_int64(0)
     args = (_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape), L.i32x3(ks), L.i32x3(st), L.i32x3(pd))
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _Timed("rulebook_conv", n=n, kvol=kvol) as rec:
         rc = lib.vx_rulebook_conv_count(*args, osh, ctypes.byref(h_n), _ptr(ws), wsb, _stream())
         L.check(rc, "vx_rulebook_conv_count")
         n_out = int(h_n.value)
@@ -202,6 +225,8 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, tr
         rc = lib.vx_rulebook_conv_emit(*args, n_out, _ptr(out_idx), _ptr(nbr), max(n_out, 1), _ptr(nbr_t),
                                        max(n, 1), _ptr(rank), _ptr(ws), wsb, _stream())
         L.check(rc, "vx_rulebook_conv_emit")
+        if rec is not None:
+            rec["nbr"], rec["n_out"] = nbr, n_out
     rb = Rulebook(nbr, n, n_out, ks, st, pd, False, spatial_shape, list(osh), out_idx, nbr_t)
     rb.out_rank = rank if n and n_out else None
     return rb
@@ -271,19 +296,12 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
     nbr, perm = rb.nbr, None
     if sort_rows and rb.n_out >= 4096 and rb.kvol > 1:
         nbr, perm = rb.sorted_table()
-    rec = None
-    if TIMING is not None:
-        rec = dict(cin=cin, cout=cout, kvol=rb.kvol, rb=rb, ev0=torch.cuda.Event(enable_timing=True),
-                   ev1=torch.cuda.Event(enable_timing=True))
-        rec["ev0"].record()
-    with torch.cuda.device(features.device):
+    with torch.cuda.device(features.device), _Timed("conv", cin=cin, cout=cout, kvol=rb.kvol, rb=rb,
+                                                   esize=features.element_size()):
         rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(nbr),
                                    max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
                                    _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(perm), _ptr(wpack),
                                    _ptr(out), _DT[features.dtype], _stream())
-    if rec is not None:
-        rec["ev1"].record()
-        TIMING.append(rec)
     L.check(rc, "vx_spconv_fwd")
     return out
 
@@ -311,7 +329,8 @@ def to_dense(features, indices, batch_size, spatial_shape):
     n, c = features.shape
     sh = triple(spatial_shape)
     dense = torch.empty((int(batch_size), c, *sh), dtype=features.dtype, device=features.device)
-    with torch.cuda.device(features.device):
+    with torch.cuda.device(features.device), _Timed("dense", n=n, c=c, numel=dense.numel(),
+                                                   esize=features.element_size()):
         rc = L.lib().vx_to_dense(_ptr(features), _ptr(indices), n, c, int(batch_size), L.i32x3(sh), _ptr(dense),
                                  _DT[features.dtype], _stream())
     L.check(rc, "vx_to_dense")
