@@ -67,6 +67,20 @@ int32_t vx_voxelize_hard(const float* d_points, int64_t n_points, int32_t n_feat
                          int64_t* d_num_voxels, int64_t* h_num_voxels, void* d_workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Batched form: n_frames clouds concatenated frame-major in d_points, frame f = points
+ * [frame_offsets[f], frame_offsets[f+1]) (HOST int64[n_frames+1], frame_offsets[0] == 0, n_frames <= 64).
+ * One launch sequence for the whole batch (replaces the per-frame loop + collate_kitti,
+ * det3d/torchie/parallel/collate.py:105-106,135-142): rows come out frame after frame, each frame in
+ * its own first-appearance order, column 0 of d_coords = f. Every frame must have <= max_voxels
+ * points (then the reference's max_voxels truncation cannot trigger); otherwise call per frame.
+ * d_num_voxels / h_num_voxels: int64[n_frames + 1] = {total, M_0, ..., M_{n_frames-1}}. */
+int32_t vx_voxelize_hard_batch(const float* d_points, int32_t n_frames, const int64_t* frame_offsets,
+                               int32_t n_feat, const float* voxel_size, const float* range,
+                               int32_t max_points, int64_t max_voxels, int32_t* d_coords,
+                               int32_t* d_num_points, float* d_voxels, float* d_mean, int64_t cap,
+                               int64_t* d_num_voxels, int64_t* h_num_voxels, void* d_workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Rulebooks (indice pairs). Stored output-major: nbr[k][o] = input row feeding output row o
  * through kernel offset k = (kz*KH + ky)*KW + kx, or -1. Row stride of nbr is nbr_ld (>= n_out).

@@ -22,11 +22,25 @@
 namespace {
 constexpr int kThreads = 256;
 
+constexpr int kMaxFrames = 64;
+
 struct VoxGeom {
   float lo[3];
   float vs[3];
   int grid[3];  // x, y, z
+  int n_frames;
+  int batch_idx0;             // frame f gets batch index batch_idx0 + f
+  long long off[kMaxFrames + 1];  // point ranges of the frames (frame-major concatenation)
 };
+
+__device__ __forceinline__ int frame_of(const VoxGeom& g, long long i) {
+  int lo = 0, hi = g.n_frames;  // off[lo] <= i < off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (i >= g.off[mid]) lo = mid; else hi = mid;
+  }
+  return lo;
+}
 
 __global__ __launch_bounds__(kThreads) void vox_init_table(VxSlot* t, long long cap) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
@@ -54,7 +68,8 @@ __global__ __launch_bounds__(kThreads) void vox_insert(const float* __restrict__
   }
   int s = -1;
   if (ok) {
-    long long key = ((long long)(int)c[2] * g.grid[1] + (int)c[1]) * g.grid[0] + (int)c[0];
+    const int f = g.n_frames > 1 ? frame_of(g, i) : 0;
+    long long key = (((long long)f * g.grid[2] + (int)c[2]) * g.grid[1] + (int)c[1]) * g.grid[0] + (int)c[0];
     long long sl = vx_hash_insert(t, mask, key);
     atomicMin(&t[sl].a, (int)i);
     atomicAdd(&t[sl].b, 1);
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void vox_assign(VxSlot* t, const int* __r
                                                        const int* __restrict__ flag,
                                                        const int* __restrict__ pos, long long n,
                                                        VoxGeom g, int max_points,
-                                                       long long max_voxels, int batch_idx,
+                                                       long long max_voxels,
                                                        int* __restrict__ coords,
                                                        int* __restrict__ num_points,
                                                        int* __restrict__ cntv,
@@ -98,8 +113,10 @@ __global__ __launch_bounds__(kThreads) void vox_assign(VxSlot* t, const int* __r
   const int x = (int)(key % g.grid[0]);
   const long long r = key / g.grid[0];
   const int y = (int)(r % g.grid[1]);
-  const int z = (int)(r / g.grid[1]);
-  *reinterpret_cast<int4*>(coords + 4ll * v) = make_int4(batch_idx, z, y, x);
+  const long long r2 = r / g.grid[1];
+  const int z = (int)(r2 % g.grid[2]);
+  const int f = (int)(r2 / g.grid[2]);
+  *reinterpret_cast<int4*>(coords + 4ll * v) = make_int4(g.batch_idx0 + f, z, y, x);
   num_points[v] = cnt < max_points ? cnt : max_points;
   cntv[v] = cnt;
 }
@@ -162,6 +179,16 @@ __global__ __launch_bounds__(kThreads) void vox_gather(const float* __restrict__
   }
 }
 
+// voxels per frame = flagged points inside the frame's point range
+__global__ void vox_frame_counts(const int* __restrict__ pos, long long n, VoxGeom g,
+                                 const long long* __restrict__ total, long long* __restrict__ counts) {
+  const int f = threadIdx.x;
+  if (f >= g.n_frames) return;
+  const long long a = g.off[f] < n ? pos[g.off[f]] : *total;
+  const long long b = g.off[f + 1] < n ? pos[g.off[f + 1]] : *total;
+  counts[f] = b - a;
+}
+
 struct VoxWs {
   VxSlot* table;
   long long cap;
@@ -203,13 +230,12 @@ extern "C" size_t vx_voxelize_workspace_bytes(int64_t n_points) {
   return carve(nullptr, n_points).bytes;
 }
 
-extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf,
-                                    const float* voxel_size, const float* range,
-                                    int32_t max_points, int64_t max_voxels, int32_t batch_idx,
-                                    int32_t* d_coords, int32_t* d_num_points, float* d_voxels,
-                                    float* d_mean, int64_t cap, int64_t* d_num_voxels,
-                                    int64_t* h_num_voxels, void* d_ws, size_t ws_bytes,
-                                    void* stream_) {
+static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const float* voxel_size,
+                             const float* range, int32_t max_points, int64_t max_voxels,
+                             int32_t batch_idx, int32_t n_frames, const int64_t* frame_offsets,
+                             int32_t* d_coords, int32_t* d_num_points, float* d_voxels,
+                             float* d_mean, int64_t cap, int64_t* d_num_voxels,
+                             int64_t* h_num_voxels, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   VX_REQUIRE(n >= 0 && n < (1ll << 30), "voxelize: n_points out of range");
   VX_REQUIRE(nf >= 3 && nf <= 8, "voxelize: n_feat must be in [3, 8]");
@@ -229,7 +255,10 @@ extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf
     return VX_ERR_WORKSPACE;
   }
   VoxGeom g;
-  long long cells = 1;
+  g.n_frames = n_frames;
+  g.batch_idx0 = batch_idx;
+  for (int f = 0; f <= n_frames; ++f) g.off[f] = frame_offsets ? frame_offsets[f] : (f ? n : 0);
+  long long cells = n_frames;
   for (int d = 0; d < 3; ++d) {
     g.lo[d] = range[d];
     g.vs[d] = voxel_size[d];
@@ -241,8 +270,9 @@ extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf
     cells *= g.grid[d];
   }
   VX_REQUIRE(cells < (1ll << 40), "voxelize: grid too large");
+  const size_t n_counts = n_frames > 1 ? (size_t)n_frames + 1 : 1;
   if (n == 0) {
-    VX_HIP(hipMemsetAsync(d_num_voxels, 0, sizeof(int64_t), stream));
+    VX_HIP(hipMemsetAsync(d_num_voxels, 0, sizeof(int64_t) * n_counts, stream));
   } else {
     const unsigned gp = (unsigned)vx_cdiv(n, kThreads);
     vox_init_table<<<(unsigned)vx_cdiv(w.cap, kThreads), kThreads, 0, stream>>>(w.table, w.cap);
@@ -259,11 +289,17 @@ extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf
       VX_HIP(hipMemsetAsync(w.cntv, 0, 4 * (size_t)n, stream));
       VX_HIP(hipMemsetAsync(w.fill, 0, 4 * (size_t)n, stream));
     }
+    // d_num_voxels[0] = total; [1 .. n_frames] = per-frame counts (batched call only)
     vox_assign<<<gp, kThreads, 0, stream>>>(w.table, w.slot_of, w.flag, w.pos, n, g, max_points,
-                                            (long long)max_voxels, batch_idx, d_coords,
+                                            (long long)max_voxels, d_coords,
                                             d_num_points, w.cntv, w.total,
                                             (long long*)d_num_voxels);
     VX_LAUNCH_CHECK();
+    if (n_frames > 1) {
+      vox_frame_counts<<<1, kMaxFrames, 0, stream>>>(w.pos, n, g, w.total,
+                                                     (long long*)d_num_voxels + 1);
+      VX_LAUNCH_CHECK();
+    }
     if (lists) {
       rc = vx_scan_exclusive_i32(w.cntv, w.off, need_cap, nullptr, w.scan_ws, w.scan_bytes,
                                  stream);
@@ -277,9 +313,44 @@ extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf
     }
   }
   if (h_num_voxels) {
-    VX_HIP(hipMemcpyAsync(h_num_voxels, d_num_voxels, sizeof(int64_t), hipMemcpyDeviceToHost,
-                          stream));
+    VX_HIP(hipMemcpyAsync(h_num_voxels, d_num_voxels, sizeof(int64_t) * n_counts,
+                          hipMemcpyDeviceToHost, stream));
     VX_HIP(hipStreamSynchronize(stream));
   }
   return VX_OK;
+}
+
+extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf,
+                                    const float* voxel_size, const float* range,
+                                    int32_t max_points, int64_t max_voxels, int32_t batch_idx,
+                                    int32_t* d_coords, int32_t* d_num_points, float* d_voxels,
+                                    float* d_mean, int64_t cap, int64_t* d_num_voxels,
+                                    int64_t* h_num_voxels, void* d_ws, size_t ws_bytes,
+                                    void* stream) {
+  return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, max_voxels, batch_idx, 1,
+                       nullptr, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
+                       h_num_voxels, d_ws, ws_bytes, stream);
+}
+
+extern "C" int32_t vx_voxelize_hard_batch(const float* d_points, int32_t n_frames,
+                                          const int64_t* frame_offsets, int32_t nf,
+                                          const float* voxel_size, const float* range,
+                                          int32_t max_points, int64_t max_voxels,
+                                          int32_t* d_coords, int32_t* d_num_points,
+                                          float* d_voxels, float* d_mean, int64_t cap,
+                                          int64_t* d_num_voxels, int64_t* h_num_voxels,
+                                          void* d_ws, size_t ws_bytes, void* stream) {
+  VX_REQUIRE(n_frames >= 1 && n_frames <= kMaxFrames && frame_offsets,
+             "voxelize_batch: 1 <= n_frames <= 64 and frame_offsets required");
+  VX_REQUIRE(frame_offsets[0] == 0, "voxelize_batch: frame_offsets[0] must be 0");
+  for (int f = 0; f < n_frames; ++f) {
+    VX_REQUIRE(frame_offsets[f + 1] >= frame_offsets[f], "voxelize_batch: offsets must be non-decreasing");
+    // no frame can produce more voxels than points: with n_f <= max_voxels truncation cannot occur
+    VX_REQUIRE(frame_offsets[f + 1] - frame_offsets[f] <= max_voxels,
+               "voxelize_batch: a frame has more points than max_voxels; use the per-frame call");
+  }
+  const int64_t n = frame_offsets[n_frames];
+  return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, (int64_t)1 << 40, 0, n_frames,
+                       frame_offsets, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
+                       h_num_voxels, d_ws, ws_bytes, stream);
 }

@@ -106,6 +106,52 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, batch_idx=0,
                 mean=mean[:m] if mean is not None else None, num_voxels=m)
 
 
+def voxelize_batch(points_list, voxel_size, pc_range, max_points, max_voxels, with_voxels=False, with_mean=True):
+    """Whole batch in one launch sequence: list of f32[N_b,F] clouds -> dict like voxelize() with coords
+    column 0 = frame index and `frame_voxels` = [M_0, ...]. Falls back to per-frame calls when a frame
+    has more points than max_voxels (only then can the reference's truncation trigger)."""
+    for p in points_list:
+        _need_gpu(p, "points")
+    b = len(points_list)
+    if b == 0 or b > 64 or any(p.shape[0] > max_voxels for p in points_list):
+        outs = [voxelize(p, voxel_size, pc_range, max_points, max_voxels, batch_idx=i, with_voxels=with_voxels,
+                         with_mean=with_mean) for i, p in enumerate(points_list)]
+        cat = lambda k: torch.cat([o[k] for o in outs]) if outs and outs[0][k] is not None else None  # noqa: E731
+        return dict(coords=cat("coords"), num_points=cat("num_points"), voxels=cat("voxels"), mean=cat("mean"),
+                    num_voxels=sum(o["num_voxels"] for o in outs), frame_voxels=[o["num_voxels"] for o in outs])
+    pts = torch.cat([p.contiguous() for p in points_list]) if b > 1 else points_list[0].contiguous()
+    if pts.dtype != torch.float32 or pts.dim() != 2:
+        raise ValueError("points must be float32 [N, F]")
+    n, f = pts.shape
+    dev = pts.device
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    rg = np.asarray(pc_range, dtype=np.float32)
+    offs = np.zeros(b + 1, dtype=np.int64)
+    np.cumsum([p.shape[0] for p in points_list], out=offs[1:])
+    cap = max(1, n)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
+    voxels = torch.empty((cap, max_points, f), dtype=torch.float32, device=dev) if with_voxels else None
+    mean = torch.empty((cap, f), dtype=torch.float32, device=dev) if with_mean else None
+    d_m = torch.zeros((b + 1,), dtype=torch.int64, device=dev)
+    h_m = (ctypes.c_int64 * (b + 1))()
+    lib = L.lib()
+    wsb = lib.vx_voxelize_workspace_bytes(n)
+    ws = _ws(wsb, dev)
+    with torch.cuda.device(dev), _Timed("voxelize", n_points=n, n_feat=f) as rec:
+        rc = lib.vx_voxelize_hard_batch(_ptr(pts), b, offs.ctypes.data_as(L.c_i64p), f, vs.ctypes.data_as(L.c_f32p),
+                                        rg.ctypes.data_as(L.c_f32p), int(max_points), int(max_voxels), _ptr(coords),
+                                        _ptr(nump), _ptr(voxels), _ptr(mean), cap, _ptr(d_m), h_m, _ptr(ws), wsb,
+                                        _stream())
+    L.check(rc, "vx_voxelize_hard_batch")
+    m = int(h_m[0])
+    per = [int(h_m[i + 1]) for i in range(b)] if b > 1 else [m]
+    if rec is not None:
+        rec["n_voxels"] = m
+    return dict(coords=coords[:m], num_points=nump[:m], voxels=voxels[:m] if voxels is not None else None,
+                mean=mean[:m] if mean is not None else None, num_voxels=m, frame_voxels=per)
+
+
 # ------------------------------------------------------------------------------------------------
 # rulebooks
 # ------------------------------------------------------------------------------------------------

@@ -87,5 +87,7 @@ def collate_voxels(frames):
 
 def voxelize_batch(generator, clouds):
     """Fused path for a list of CUDA clouds: -> (mean f32[sum M,F], coords int32[sum M,4], num_points)."""
-    outs = [generator.generate_mean(c, batch_idx=b) for b, c in enumerate(clouds)]
-    return (torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
+    r = ops.voxelize_batch(list(clouds), generator.voxel_size, generator.point_cloud_range,
+                           generator.max_num_points_per_voxel, generator._max_voxels, with_voxels=False,
+                           with_mean=True)
+    return r["mean"], r["coords"], r["num_points"]
