@@ -145,3 +145,33 @@ def test_shard_frames():
     assert shard_frames(10, 3, 4) == [3, 7, 1]      # padded like DistributedSampler
     got = sorted(i for r in range(8) for i in shard_frames(32, r, 8))
     assert got == list(range(32))
+
+
+def test_registries_and_build_from_cfg():
+    """det3d/utils/registry.py:6-78, models/registry.py:3-4: name -> class registries + dict construction."""
+    import vista_amd.models  # noqa: F401  (registers the classes)
+    import vista_amd.voxel  # noqa: F401
+    from vista_amd.registry import BACKBONES, PIPELINES, READERS, Registry, build_from_cfg
+    assert set(BACKBONES.module_dict) >= {"SpMiddleResNetFHD", "MultiViewBackbone"}
+    assert "VoxelFeatureExtractorV3" in READERS and "Voxelization" in PIPELINES
+    net = build_from_cfg(dict(type="SpMiddleResNetFHD", num_input_features=5, ds_factor=8), BACKBONES)
+    assert type(net).__name__ == "SpMiddleResNetFHD"
+    rd = build_from_cfg(dict(type="VoxelFeatureExtractorV3"), READERS, default_args=dict(num_input_features=5))
+    assert rd.num_input_features == 5
+    assert build_from_cfg(dict(type=dict), BACKBONES, dict(a=1)) == {"a": 1}      # a class instead of a name
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(type="NoSuchBackbone"), BACKBONES)
+    with pytest.raises(TypeError):
+        build_from_cfg(dict(type=3), BACKBONES)
+    with pytest.raises(AssertionError):
+        build_from_cfg(dict(kind="x"), BACKBONES)
+    r = Registry("t")
+
+    @r.register_module
+    class A:
+        pass
+    assert r.get("A") is A and r.get("B") is None and r.name == "t"
+    with pytest.raises(KeyError):
+        r.register_module(A)
+    with pytest.raises(TypeError):
+        r.register_module(lambda: 0)

@@ -99,6 +99,36 @@ def test_voxel_generator_api(dev):
     np.testing.assert_array_equal(cc[:d["coords"].shape[0], 1:], d["coords"])
 
 
+def test_voxelization_double_flip_stage(dev):
+    """preprocess.py:210-254: three more voxelizations of the flipped clouds (test_aug.py:53-77 flips);
+    each dict must equal the oracle's voxelization of that cloud, bit for bit."""
+    from oracle import voxelize_np as ov
+    from vista_amd.voxel import Voxelization
+    d = np.load(os.path.join(G, "voxel_tiny_1sweep.npz"))
+    m = MAN["tiny_1sweep"]
+    pts = d["points"]
+    clouds = {"points": pts}
+    for key, sx, sy in (("yflip", 1, -1), ("xflip", -1, 1), ("double_flip", -1, -1)):
+        q = pts.copy()
+        q[:, 0] *= sx
+        q[:, 1] *= sy
+        clouds[f"{key}_points"] = q
+    stage = Voxelization(cfg=dict(range=m["range"], voxel_size=m["voxel_size"], max_points_in_voxel=m["max_points"],
+                                  max_voxel_num=m["max_voxels"], double_flip=True))
+    res, _ = stage(dict(lidar={k: torch.from_numpy(v).to(dev) for k, v in clouds.items()}, mode="val"), None)
+    for key in ("", "yflip_", "xflip_", "double_flip_"):
+        vd = res["lidar"][f"{key}voxels"]
+        v, c, n = ov.voxelize(clouds[f"{key}points"], m["voxel_size"], m["range"], m["max_points"], m["max_voxels"])
+        np.testing.assert_array_equal(vd["coordinates"].cpu().numpy(), c)
+        np.testing.assert_array_equal(vd["num_points"].cpu().numpy(), n)
+        np.testing.assert_array_equal(vd["voxels"].cpu().numpy(), v)
+        assert vd["num_voxels"].dtype == np.int64 and vd["num_voxels"][0] == c.shape[0]
+        assert ("range" in vd) == bool(key) and ("size" in vd) == bool(key)
+    # training mode never takes the flip branch (preprocess.py:181)
+    res, _ = stage(dict(lidar=dict(points=torch.from_numpy(pts).to(dev)), mode="train"), None)
+    assert "yflip_voxels" not in res["lidar"]
+
+
 # ---------------------------------------------------------------------------- rulebooks
 def random_sites(rng, batch, shape, n):
     vol = int(np.prod(shape))

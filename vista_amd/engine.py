@@ -124,6 +124,12 @@ class FusedBackbone:
     def __call__(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
         st = _State(voxel_features, coors.int().contiguous(), sparse_shape, int(batch_size), {})
+        # geometry pass first: every host sync (output row counts of the strided convs) happens before the
+        # feature pass, which then queues its ~25 launches without waiting on the GPU
+        geo = _run(self.middle, st, geom_only=True)
+        if self.kind == "MultiViewBackbone":
+            _run(self.bev, geo, geom_only=True)
+            _run(self.rv, geo, geom_only=True)
         mid = _run(self.middle, st)
         if self.kind == "SpMiddleResNetFHD":
             d = ops.to_dense(mid.feat, mid.idx, mid.batch, mid.shape)

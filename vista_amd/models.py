@@ -15,6 +15,7 @@ from torch import nn
 
 import spconv.pytorch as spconv
 
+from .registry import BACKBONES, READERS
 from .synth import BEV_LAYERS, RV_LAYERS, middle_layers
 
 
@@ -29,6 +30,7 @@ def build_norm_layer(cfg, num_features):
     return "bn", layer
 
 
+@READERS.register_module
 class VoxelFeatureExtractorV3(nn.Module):
     def __init__(self, num_input_features=4, norm_cfg=None, name="VoxelFeatureExtractorV3"):
         super().__init__()
@@ -94,6 +96,7 @@ def _sequential(spec, norm_cfg, keys):
     return spconv.SparseSequential(*mods)
 
 
+@BACKBONES.register_module
 class SpMiddleResNetFHD(nn.Module):
     def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
         super().__init__()
@@ -114,6 +117,7 @@ class SpMiddleResNetFHD(nn.Module):
         return ret
 
 
+@BACKBONES.register_module
 class MultiViewBackbone(nn.Module):
     def __init__(self, num_input_features=128, norm_cfg=None, name="MultiViewBackbone", **kwargs):
         super().__init__()

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .registry import PIPELINES
 
 
 class VoxelGenerator:
@@ -30,6 +31,16 @@ class VoxelGenerator:
         r = ops.voxelize(points, self._voxel_size, self._point_cloud_range, self._max_num_points,
                          self._max_voxels, with_voxels=True, with_mean=False)
         return r["voxels"], r["coords"][:, 1:], r["num_points"]
+
+    def generate_many(self, clouds):
+        """generate() for several clouds in one launch sequence -> list of (voxels, coordinates, num_points)."""
+        r = ops.voxelize_batch(list(clouds), self._voxel_size, self._point_cloud_range, self._max_num_points,
+                               self._max_voxels, with_voxels=True, with_mean=False)
+        out, lo = [], 0
+        for m in r["frame_voxels"]:
+            out.append((r["voxels"][lo:lo + m], r["coords"][lo:lo + m, 1:], r["num_points"][lo:lo + m]))
+            lo += m
+        return out
 
     def generate_mean(self, points, batch_idx=0):
         """Fused voxelization + mean VFE: -> (mean f32[M,F], coordinates int32[M,4] (b,z,y,x), num_points)."""
@@ -54,8 +65,16 @@ class VoxelGenerator:
         return self._grid_size
 
 
+@PIPELINES.register_module
 class Voxelization:
-    """Pipeline stage: res["lidar"]["points"] -> res["lidar"]["voxels"] dict (preprocess.py:202-208)."""
+    """Pipeline stage: res["lidar"]["points"] -> res["lidar"]["voxels"] dict (preprocess.py:175-208) and,
+    with cfg.double_flip outside training, the three flipped clouds' dicts (preprocess.py:210-254).
+
+    The four clouds of the double-flip case go through ONE batched launch sequence; each dict is
+    bit-identical to a separate generate() call. Box filtering of the training branch (:182-189) is data
+    augmentation and stays with the caller."""
+
+    FLIPS = ("yflip", "xflip", "double_flip")
 
     def __init__(self, **kwargs):
         cfg = kwargs.get("cfg", None)
@@ -64,15 +83,34 @@ class Voxelization:
         self.voxel_size = get("voxel_size")
         self.max_points_in_voxel = get("max_points_in_voxel")
         self.max_voxel_num = get("max_voxel_num")
+        self.drop_rate = get("drop_rate", 0)
         self.faster = get("faster", False)
+        self.double_flip = get("double_flip", False)
         self.voxel_generator = VoxelGenerator(self.voxel_size, self.range, self.max_points_in_voxel,
                                               self.max_voxel_num, self.faster)
 
+    def _dict(self, voxels, coordinates, num_points, flipped):
+        g = self.voxel_generator
+        d = dict(voxels=voxels, coordinates=coordinates, num_points=num_points,
+                 num_voxels=np.array([voxels.shape[0]], dtype=np.int64), shape=g.grid_size)
+        if flipped:
+            d.update(range=g.point_cloud_range, size=g.voxel_size)
+        return d
+
     def __call__(self, res, info):
-        voxels, coordinates, num_points = self.voxel_generator.generate(res["lidar"]["points"])
-        res["lidar"]["voxels"] = dict(
-            voxels=voxels, coordinates=coordinates, num_points=num_points,
-            num_voxels=np.array([voxels.shape[0]], dtype=np.int64), shape=self.voxel_generator.grid_size)
+        mode = res.get("mode", "val")
+        lidar = res["lidar"]
+        if self.double_flip and mode != "train":
+            triples = self.voxel_generator.generate_many([lidar["points"]] + [lidar[f"{k}_points"] for k in self.FLIPS])
+            lidar["voxels"] = self._dict(*triples[0], flipped=False)
+            for k, t in zip(self.FLIPS, triples[1:]):
+                lidar[f"{k}_voxels"] = self._dict(*t, flipped=True)
+            return res, info
+        voxels, coordinates, num_points = self.voxel_generator.generate(lidar["points"])
+        if mode == "train" and self.drop_rate > 0:
+            keep = torch.rand(voxels.shape[0], device=voxels.device) >= self.drop_rate
+            voxels, coordinates, num_points = voxels[keep], coordinates[keep], num_points[keep]
+        lidar["voxels"] = self._dict(voxels, coordinates, num_points, flipped=False)
         return res, info
 
 
