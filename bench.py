@@ -25,7 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from vista_amd import models, ops  # noqa: E402
-from vista_amd.engine import FusedBackbone  # noqa: E402
+from vista_amd.engine import FramePipeline, FusedBackbone  # noqa: E402
 from vista_amd.synth import GEOMETRIES, backbone_state_dict, grid_size, lidar_cloud  # noqa: E402
 from vista_amd.voxel import VoxelGenerator, voxelize_batch  # noqa: E402
 
@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--backbone", default="SpMiddleResNetFHD", choices=["SpMiddleResNetFHD", "MultiViewBackbone"],
                     help="MultiViewBackbone needs --geometry VISTA (multiview.py:88-106)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="sub-batches of a step on alternating HIP streams (vista_amd.engine.FramePipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     return ap.parse_args()
@@ -76,8 +78,12 @@ def cpu_baseline(geometry):
                       f"backbone {1e3 * (t2 - t1):.0f} ms (C/OpenMP, {threads} threads)"}
 
 
-def timed_infer(gen, engine, frames, grid, steps, warmup, barrier):
+def timed_infer(gen, engine, frames, grid, steps, warmup, barrier, streams=1):
+    pipe = FramePipeline(gen, engine, groups=streams) if streams > 1 else None
+
     def step():
+        if pipe is not None:
+            return pipe(frames, grid, join=False)
         mean, coords, _ = voxelize_batch(gen, frames)
         return engine(mean, coords, len(frames), grid)
     for _ in range(warmup):
@@ -222,7 +228,7 @@ def main():
     engine = FusedBackbone(net, dtype=dtype)
     frames = make_frames(a.geometry, a.batch, rank, dev)
 
-    dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier)
+    dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier, a.streams)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

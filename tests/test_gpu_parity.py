@@ -523,3 +523,29 @@ def test_voxelize_batch_equals_per_frame(dev):
     # a frame with more points than max_voxels takes the per-frame path (truncation semantics kept)
     small = ops.voxelize_batch(clouds, vs, rg, T, 100, with_voxels=False)
     assert small["frame_voxels"] == [100, 0, 100, 100]
+
+
+def test_frame_pipeline_bitwise_equals_single_batch(dev):
+    """Sub-batches on alternating streams (engine.FramePipeline) == one batch, bit for bit."""
+    from vista_amd import models
+    from vista_amd.engine import FramePipeline, FusedBackbone
+    from vista_amd.synth import GEOMETRIES, backbone_state_dict, grid_size, lidar_cloud
+    from vista_amd.voxel import VoxelGenerator, voxelize_batch
+    rg, vs, T, mv = GEOMETRIES["SMALL"]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
+                                       backbone_state_dict("SpMiddleResNetFHD")).to(dev).eval()
+    eng = FusedBackbone(net)
+    frames = [torch.from_numpy(lidar_cloud(seed=s, sweeps=1)).to(dev) for s in range(5)]
+    mean, coords, _ = voxelize_batch(gen, frames)
+    ref = eng(mean, coords, len(frames), grid)
+    pipe = FramePipeline(gen, eng, groups=2)
+    for _ in range(3):                       # call 1 learns the shape, calls 2-3 run on two streams
+        out = pipe(frames, grid)
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape and torch.equal(out, ref)
+    a = pipe(frames, grid, join=False)       # un-joined calls pipeline; synchronise before use
+    b = pipe(frames[:3], grid, join=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref[:3])

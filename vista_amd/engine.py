@@ -121,7 +121,7 @@ class FusedBackbone:
             raise TypeError(f"unsupported backbone {self.kind}")
 
     @torch.no_grad()
-    def __call__(self, voxel_features, coors, batch_size, input_shape):
+    def __call__(self, voxel_features, coors, batch_size, input_shape, out=None):
         sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
         st = _State(voxel_features, coors.int().contiguous(), sparse_shape, int(batch_size), {})
         # geometry pass first: every host sync (output row counts of the strided convs) happens before the
@@ -132,9 +132,11 @@ class FusedBackbone:
             _run(self.rv, geo, geom_only=True)
         mid = _run(self.middle, st)
         if self.kind == "SpMiddleResNetFHD":
-            d = ops.to_dense(mid.feat, mid.idx, mid.batch, mid.shape)
+            d = ops.to_dense(mid.feat, mid.idx, mid.batch, mid.shape, out=out)
             n, c, dd, h, w = d.shape
             return d.view(n, c * dd, h, w) if self.mode == "bev" else d
+        if out is not None:
+            raise NotImplementedError("out= is only supported for SpMiddleResNetFHD")
         b = _run(self.bev, mid)
         bev = ops.to_dense(b.feat, b.idx, b.batch, b.shape)
         n, c, d, h, w = bev.shape
@@ -144,3 +146,53 @@ class FusedBackbone:
         n, c, d, h, w = rv.shape
         rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)
         return bev, rv
+
+
+class FramePipeline:
+    """Voxelization + backbone for a list of frames, split into `groups` sub-batches that run on
+    alternating HIP streams. Frames are independent, so the sub-batches share nothing; while one
+    group's host syncs (voxel / output-row counts) and small rulebook kernels are in progress, the other
+    group's sparse convs keep the CUs busy, and one kernel's last partial round of workgroups overlaps the
+    next kernel's first. Results are bitwise identical to the single-batch call (every output row's
+    accumulation order is independent of where its tile sits)."""
+
+    def __init__(self, generator, engine, groups=2):
+        self.gen, self.engine, self.groups = generator, engine, max(1, int(groups))
+        self.streams = None
+
+    def __call__(self, frames, grid, join=True):
+        """-> dense BEV tensor [len(frames), C*D, H, W]. join=False leaves the side streams un-joined so
+        that consecutive calls pipeline; the caller then synchronises (torch.cuda.synchronize()) before use."""
+        from .voxel import voxelize_batch
+        dev = frames[0].device
+        if self.groups == 1 or len(frames) < 2:
+            mean, coords, _ = voxelize_batch(self.gen, frames)
+            return self.engine(mean, coords, len(frames), grid)
+        if self.engine.kind != "SpMiddleResNetFHD":
+            raise NotImplementedError("FramePipeline drives SpMiddleResNetFHD")
+        if self.streams is None:
+            # first call: single stream, learns the output geometry
+            mean, coords, _ = voxelize_batch(self.gen, frames)
+            first = self.engine(mean, coords, len(frames), grid)
+            self._shape, self._dtype = tuple(first.shape[1:]), first.dtype
+            self.streams = [torch.cuda.Stream(dev) for _ in range(self.groups)]
+            return first
+        main = torch.cuda.current_stream(dev)
+        per = -(-len(frames) // self.groups)
+        out = torch.empty((len(frames), *self._shape), dtype=self._dtype, device=dev)   # on the caller's stream
+        used = []
+        for g in range(self.groups):
+            fr = frames[g * per:(g + 1) * per]
+            if not fr:
+                break
+            s = self.streams[g]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                mean, coords, _ = voxelize_batch(self.gen, fr)
+                self.engine(mean, coords, len(fr), grid, out=out[g * per:g * per + len(fr)])
+            out.record_stream(s)
+            used.append(s)
+        if join:
+            for s in used:
+                main.wait_stream(s)
+        return out

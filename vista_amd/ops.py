@@ -367,14 +367,22 @@ def conv_dgrad(grad_out, weight, rb):
     return din
 
 
-def to_dense(features, indices, batch_size, spatial_shape):
-    """-> [B, C, D, H, W] (channels first, contiguous)."""
+def to_dense(features, indices, batch_size, spatial_shape, out=None):
+    """-> [B, C, D, H, W] (channels first, contiguous); `out` = a contiguous tensor of that many elements to fill
+    instead of allocating (e.g. a slice of a larger batch)."""
     _need_gpu(features, "features")
     features = features.contiguous()
     indices = indices.contiguous()
     n, c = features.shape
     sh = triple(spatial_shape)
-    dense = torch.empty((int(batch_size), c, *sh), dtype=features.dtype, device=features.device)
+    shape = (int(batch_size), c, *sh)
+    if out is None:
+        dense = torch.empty(shape, dtype=features.dtype, device=features.device)
+    else:
+        if (not out.is_contiguous() or out.dtype != features.dtype or out.device != features.device
+                or out.numel() != int(np.prod(shape))):
+            raise ValueError(f"out must be a contiguous {features.dtype} tensor of {shape} elements on {features.device}")
+        dense = out.view(shape)
     with torch.cuda.device(features.device), _Timed("dense", n=n, c=c, numel=dense.numel(),
                                                    esize=features.element_size()):
         rc = L.lib().vx_to_dense(_ptr(features), _ptr(indices), n, c, int(batch_size), L.i32x3(sh), _ptr(dense),
