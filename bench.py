@@ -254,6 +254,12 @@ def main():
             # batch-1 latency variant of the same workload (not part of `value`)
             dt1, _, _ = timed_infer(gen, engine, frames[:1], grid, max(3, a.steps), 2, barrier)
             res["variants"] = {"batch1_frames_per_s": max(3, a.steps) / dt1}
+            if a.streams == 1 and a.backbone == "SpMiddleResNetFHD" and a.batch >= 2:
+                # same step as two half-batches on alternating HIP streams (engine.FramePipeline): higher
+                # throughput, but kernels of the two streams overlap, so per-kernel HIP-event times (and the
+                # roofline above) are only meaningful in the single-stream run that `value` comes from
+                dt2, _, _ = timed_infer(gen, engine, frames, grid, a.steps, 2, barrier, streams=2)
+                res["variants"]["two_stream_frames_per_s"] = a.batch * a.steps / dt2
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.geometry)
         print(json.dumps(res))
