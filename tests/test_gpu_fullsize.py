@@ -1,0 +1,188 @@
+"""GPU parity at BASELINE.json's FULL sizes (FHD [41,1440,1440], ~247k points per frame; STRESS 0.05 m,
+~1M points): one frame end to end against the CPU oracle (it finishes in seconds on the box's cores), and
+size-independent properties where the oracle would be too slow: coordinate consistency of every rulebook
+entry, sortedness / uniqueness of output sites, subm symmetry, pair-count conservation, batch invariance
+(bitwise), linearity of a conv layer. All calls go through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _setup(geometry, seeds, sweeps, dev):
+    from vista_amd.synth import GEOMETRIES, grid_size, lidar_cloud
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES[geometry]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    clouds = [lidar_cloud(seed=s, sweeps=sweeps) for s in seeds]
+    grid = grid_size(rg, vs).tolist()
+    return gen, clouds, grid, (rg, vs, T, mv)
+
+
+def _lin(c, shape):
+    c = c.long()
+    return ((c[:, 0] * shape[0] + c[:, 1]) * shape[1] + c[:, 2]) * shape[2] + c[:, 3]
+
+
+def _check_rulebook(rb, in_idx, subm):
+    """Every entry nbr[k][o] = i must satisfy in_coord(i) == out_coord(o) * stride - pad + k (same frame);
+    every (i, k) whose target output exists must be present (conservation: counted through the transpose)."""
+    ks, st, pd = rb.ksize, rb.stride, rb.padding
+    out_idx = rb.out_indices
+    lin = _lin(out_idx, rb.out_shape)
+    if not subm:
+        assert bool((lin[1:] > lin[:-1]).all()), "strided-conv output sites must be sorted and unique"
+    total = 0
+    k = 0
+    for kz in range(ks[0]):
+        for ky in range(ks[1]):
+            for kx in range(ks[2]):
+                row = rb.nbr[k]
+                o = torch.nonzero(row >= 0, as_tuple=True)[0]
+                i = row[o].long()
+                total += int(o.numel())
+                oc, ic = out_idx[o].long(), in_idx[i].long()
+                assert torch.equal(ic[:, 0], oc[:, 0])
+                for d, kk in ((1, kz), (2, ky), (3, kx)):
+                    assert torch.equal(ic[:, d], oc[:, d] * st[d - 1] - pd[d - 1] + kk), (k, d)
+                k += 1
+    return total
+
+
+def _expected_pairs(in_idx, rb):
+    """Number of (input, offset) combinations whose output coordinate is on the output grid: every one of
+    them must appear in the rulebook of a regular sparse conv (all such outputs are active)."""
+    ks, st, pd = rb.ksize, rb.stride, rb.padding
+    c = in_idx.long()
+    cnt = torch.ones(c.shape[0], dtype=torch.long, device=c.device)
+    for d in range(3):
+        per = torch.zeros_like(cnt)
+        for kk in range(ks[d]):
+            t = c[:, d + 1] + pd[d] - kk
+            ok = (t >= 0) & (t % st[d] == 0) & (t // st[d] < rb.out_shape[d])
+            per += ok.long()
+        cnt *= per
+    return int(cnt.sum().item())
+
+
+def test_fhd_frame_end_to_end_vs_oracle(dev):
+    """BASELINE configs[0]/[1] at full size, one frame: voxels and every stage's site set bit-exact, dense
+    output within 1e-4 relative (fp32), module path and fused engine."""
+    from oracle import backbone_oracle as bo
+    from oracle import spconv_oracle as so
+    from oracle import voxelize_np as ov
+    from vista_amd import models, ops
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, (rg, vs, T, mv) = _setup("FHD", [0], 10, dev)
+    mean, coords, nump = voxelize_batch(gen, [torch.from_numpy(clouds[0]).to(dev)])
+    v, c, n = ov.voxelize(clouds[0], vs, rg, T, mv)
+    o_coords = ov.collate_coords([c])
+    np.testing.assert_array_equal(coords.cpu().numpy(), o_coords)
+    np.testing.assert_array_equal(nump.cpu().numpy(), n)
+    o_feat = ov.mean_vfe(v, n)
+    np.testing.assert_allclose(mean.cpu().numpy(), o_feat, rtol=1e-6, atol=1e-6)
+    # site sets of the three strided stages + last conv, bit-exact (canonical order = sorted linear index)
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    g_idx, g_shape, o_idx, o_shape = coords, shape, o_coords, shape
+    for ks, st, pd in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                       ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
+        rb = ops.rulebook_conv(g_idx, 1, g_shape, ks, st, pd)
+        oc, onbr, osh = so.rulebook_conv(o_idx, o_shape, ks, st, pd)
+        np.testing.assert_array_equal(rb.out_indices.cpu().numpy(), oc)
+        np.testing.assert_array_equal(rb.nbr.cpu().numpy(), onbr)
+        g_idx, g_shape, o_idx, o_shape = rb.out_indices, rb.out_shape, oc, list(osh)
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).to(dev).eval()
+    ref, _ = bo.sp_middle_resnet_fhd(o_feat, o_coords, 1, grid, sd)
+    with torch.no_grad():
+        out_mod = net(mean, coords, 1, grid).cpu().numpy()
+    out_fused = FusedBackbone(net)(mean, coords, 1, grid).cpu().numpy()
+    assert out_mod.shape == ref.shape == out_fused.shape == (1, 256, 180, 180)
+    scale = np.abs(ref).max()
+    assert np.abs(out_mod - ref).max() <= 1e-4 * scale      # north_star: 1e-4 relative in fp32
+    assert np.abs(out_fused - ref).max() <= 1e-4 * scale
+    out_bf16 = FusedBackbone(net, dtype=torch.bfloat16)(mean, coords, 1, grid).float().cpu().numpy()
+    assert np.abs(out_bf16 - ref).max() <= 2e-2 * scale     # north_star: 2e-2 in bf16
+
+
+@pytest.mark.parametrize("geometry,seeds,sweeps", [("FHD", [0, 1, 2, 3], 10), ("STRESS", [7], 40)])
+def test_fullsize_rulebook_properties(geometry, seeds, sweeps, dev):
+    from vista_amd import ops
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, _ = _setup(geometry, seeds, sweeps, dev)
+    batch = len(seeds)
+    mean, coords, nump = voxelize_batch(gen, [torch.from_numpy(c).to(dev) for c in clouds])
+    assert int(nump.min()) >= 1 and mean.shape[0] == coords.shape[0]
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    # voxels are unique per frame
+    lin = _lin(coords, shape)
+    assert torch.unique(lin).numel() == lin.numel()
+    idx, rank = coords, None
+    for ks, st, pd in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                       ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
+        # submanifold rulebook of the current site set (hash path at stage 0, rank-table path after)
+        rs = ops.rulebook_subm(idx, batch, shape, 3, rank=rank)
+        n_pairs = _check_rulebook(rs, idx, subm=True)
+        assert torch.equal(rs.nbr[13], torch.arange(idx.shape[0], dtype=torch.int32, device=dev))  # centre offset
+        # symmetry: nbr[26-k][j] == i  <=>  nbr[k][i] == j
+        for k in (0, 5, 12):
+            o = torch.nonzero(rs.nbr[k] >= 0, as_tuple=True)[0]
+            i = rs.nbr[k][o].long()
+            assert torch.equal(rs.nbr[26 - k][i].long(), o)
+        assert n_pairs == int((rs.nbr >= 0).sum())
+        # strided rulebook to the next stage
+        rb = ops.rulebook_conv(idx, batch, shape, ks, st, pd, transpose=True)
+        got = _check_rulebook(rb, idx, subm=False)
+        assert got == _expected_pairs(idx, rb), "a strided conv must hold every (input, offset) on the output grid"
+        assert got == int((rb.nbr_t >= 0).sum())
+        kk, ii = torch.nonzero(rb.nbr_t >= 0, as_tuple=True)
+        assert torch.equal(rb.nbr[kk, rb.nbr_t[kk, ii].long()].long(), ii)      # transpose table is the inverse
+        pairs, num = rb.pairs()
+        assert int(num.sum()) == got
+        idx, shape, rank = rb.out_indices, rb.out_shape, rb.out_rank
+
+
+def test_fhd_batch_invariance_and_linearity(dev):
+    """A frame's output does not depend on what else is in the batch (bitwise), and a conv layer is linear."""
+    from vista_amd import models, ops
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, _ = _setup("FHD", [0, 1, 2], 10, dev)
+    frames = [torch.from_numpy(c).to(dev) for c in clouds]
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
+                                       backbone_state_dict("SpMiddleResNetFHD")).to(dev).eval()
+    eng = FusedBackbone(net)
+    mean, coords, _ = voxelize_batch(gen, frames)
+    full = eng(mean, coords, 3, grid)
+    for b in (0, 2):
+        m1, c1, _ = voxelize_batch(gen, [frames[b]])
+        one = eng(m1, c1, 1, grid)
+        assert torch.equal(one[0], full[b])
+    # linearity of one full-size SubM layer (C=64 -> 64), no bias / activation
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    rb1 = ops.rulebook_conv(coords, 3, shape, 3, 2, 1)
+    rb2 = ops.rulebook_conv(rb1.out_indices, 3, rb1.out_shape, 3, 2, 1)
+    rs = ops.rulebook_subm(rb2.out_indices, 3, rb2.out_shape, 3, rank=rb2.out_rank)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(rs.n_in, 64, generator=g).to(dev)
+    y = torch.randn(rs.n_in, 64, generator=g).to(dev)
+    w = (torch.randn(64, 3, 3, 3, 64, generator=g) / np.sqrt(27 * 64)).to(dev)
+    fx, fy = ops.conv_fwd(x, w, rs), ops.conv_fwd(y, w, rs)
+    fxy = ops.conv_fwd(2.0 * x - 0.5 * y, w, rs)
+    err = (fxy - (2.0 * fx - 0.5 * fy)).abs().max()
+    assert float(err) <= 1e-5 * float(fxy.abs().max())
+    # dgrad is the adjoint of fwd: <conv(x), g> == <x, dgrad(g)>
+    gy = torch.randn(rs.n_out, 64, generator=g).to(dev)
+    lhs = (fx.double() * gy.double()).sum()
+    rhs = (x.double() * ops.conv_dgrad(gy, w, rs).double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs))
