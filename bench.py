@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--backbone", default="SpMiddleResNetFHD", choices=["SpMiddleResNetFHD", "MultiViewBackbone"],
                     help="MultiViewBackbone needs --geometry VISTA (multiview.py:88-106)")
+    ap.add_argument("--full-net", action="store_true",
+                    help="BASELINE configs[2]: MultiViewBackbone + dense tail (necks, cross-view attention, OHS head; "
+                         "stock PyTorch-ROCm ops) on the VISTA geometry")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of a step on alternating HIP streams (vista_amd.engine.FramePipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,14 +81,18 @@ def cpu_baseline(geometry):
                       f"backbone {1e3 * (t2 - t1):.0f} ms (C/OpenMP, {threads} threads)"}
 
 
-def timed_infer(gen, engine, frames, grid, steps, warmup, barrier, streams=1):
+def timed_infer(gen, engine, frames, grid, steps, warmup, barrier, streams=1, tail=None):
     pipe = FramePipeline(gen, engine, groups=streams) if streams > 1 else None
 
     def step():
         if pipe is not None:
             return pipe(frames, grid, join=False)
         mean, coords, _ = voxelize_batch(gen, frames)
-        return engine(mean, coords, len(frames), grid)
+        out = engine(mean, coords, len(frames), grid)
+        if tail is not None:
+            with torch.no_grad():
+                out = tail(*out)
+        return out
     for _ in range(warmup):
         step()
     barrier()
@@ -227,8 +234,17 @@ def main():
                                        backbone_state_dict(a.backbone)).to(dev).eval()
     engine = FusedBackbone(net, dtype=dtype)
     frames = make_frames(a.geometry, a.batch, rank, dev)
+    tail = None
+    if a.full_net:
+        if a.geometry != "VISTA" or a.backbone != "MultiViewBackbone" or a.streams != 1:
+            raise SystemExit("--full-net needs --geometry VISTA --backbone MultiViewBackbone (ohs.py:44-47 fixes the map sizes)")
+        from vista_amd.dense_tail import OHS_Multiview
+        torch.manual_seed(1234)     # dense-tail weights: torch default init, BN in eval mode with default statistics
+        det = OHS_Multiview().eval()
+        det.backbone = None         # the sparse part runs through the fused engine above
+        tail = det.to(dev).to(dtype).dense_tail
 
-    dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier, a.streams)
+    dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier, a.streams, tail)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -236,7 +252,9 @@ def main():
     total_frames = world * a.batch * a.steps
     sweeps = 40 if a.geometry == "STRESS" else 10
     res = {
-        "metric": f"backbone frames/sec (voxelize + mean VFE + {a.backbone} forward)",
+        "metric": (f"backbone frames/sec (voxelize + mean VFE + {a.backbone} forward)" if not a.full_net else
+                   "full-net frames/sec (voxelize + mean VFE + MultiViewBackbone + necks + cross-view attention + "
+                   "OHS head forward; no loss / box decode / NMS)"),
         "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16",
@@ -252,7 +270,7 @@ def main():
         res["phases"] = phase_report(timing, a.steps, a.batch)
         if world == 1 and not a.no_variants:
             # batch-1 latency variant of the same workload (not part of `value`)
-            dt1, _, _ = timed_infer(gen, engine, frames[:1], grid, max(3, a.steps), 2, barrier)
+            dt1, _, _ = timed_infer(gen, engine, frames[:1], grid, max(3, a.steps), 2, barrier, 1, tail)
             res["variants"] = {"batch1_frames_per_s": max(3, a.steps) / dt1}
             if a.streams == 1 and a.backbone == "SpMiddleResNetFHD" and a.batch >= 2:
                 # same step as two half-batches on alternating HIP streams (engine.FramePipeline): higher

@@ -186,3 +186,46 @@ def test_fhd_batch_invariance_and_linearity(dev):
     lhs = (fx.double() * gy.double()).sum()
     rhs = (x.double() * ops.conv_dgrad(gy, w, rs).double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs))
+
+
+def test_vista_full_net_forward(dev):
+    """BASELINE configs[2] shape check at full size: one VISTA frame through MultiViewBackbone + dense tail; the
+    dense tail on the GPU (MIOpen / rocBLAS) against the same modules on the CPU fed the same backbone maps."""
+    from vista_amd import models
+    from vista_amd.dense_tail import OHS_Multiview, VISTA_TASKS
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, _ = _setup("VISTA", [0], 10, dev)
+    torch.manual_seed(5)
+    det = OHS_Multiview().eval()
+    models.load_numpy_state_dict(det.backbone, backbone_state_dict("MultiViewBackbone"))
+    # non-trivial BatchNorm statistics in the dense tail
+    with torch.no_grad():
+        for m in det.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    cpu_state = {k: v.clone() for k, v in det.state_dict().items()}
+    det = det.to(dev)
+    mean, coords, nump = voxelize_batch(gen, [torch.from_numpy(clouds[0]).to(dev)])
+    bev, rv = FusedBackbone(det.backbone)(mean, coords, 1, grid)
+    assert bev.shape == (1, 640, 160, 160) and rv.shape == (1, 640, 160, 12)     # multiview.py:101-105, ohs.py:44-47
+    with torch.no_grad():
+        preds = det.dense_tail(bev, rv)
+        # the module path (reader + backbone modules + tail) gives the same predictions as engine + tail
+        ex = dict(voxels=mean[:, None, :], num_points=torch.ones_like(nump), coordinates=coords,
+                  num_voxels=np.array([coords.shape[0]]), shape=[np.array(grid)])
+        preds_mod = det(ex)
+    ref = OHS_Multiview().eval()
+    ref.load_state_dict(cpu_state)
+    with torch.no_grad():
+        preds_cpu = ref.dense_tail(bev.cpu(), rv.cpu())
+    assert len(preds) == len(VISTA_TASKS)
+    for p, q, c, t in zip(preds, preds_mod, preds_cpu, VISTA_TASKS):
+        assert p["cls_preds"].shape == (1, 160, 160, t["num_class"]) and p["box_preds"].shape == (1, 160, 160, 10)
+        for k in ("cls_preds", "box_preds"):
+            assert bool(torch.isfinite(p[k]).all())
+            s = float(c[k].abs().max())
+            assert float((p[k].cpu() - c[k]).abs().max()) <= 2e-3 * s       # fp32 conv algorithms differ (MIOpen vs CPU)
+            assert float((q[k] - p[k]).abs().max()) <= 2e-3 * s

@@ -1,0 +1,380 @@
+"""Dense tail of the full VISTA network, forward only, on stock PyTorch-ROCm ops:
+the 2-D necks over the BEV and RV maps, the decoupled cross-view attention, and the decoupled OHS head.
+It exists so that BASELINE configs[2] ("over full VISTA net") can be measured on top of the sparse backbone;
+the hot path of this repo is the sparse part, this file is plumbing around it (MIOpen convs, rocBLAS GEMMs).
+
+Own restatement with the reference's module / parameter names, so a reference state_dict loads key for key:
+  RPN / RPNT                       det3d/models/necks/rpn.py:17-156, rpnt.py:13-76
+  Cross_Attention_Decouple         det3d/models/necks/attention.py:14-343
+  DeepMultiGroupOHSHeadClear_Decouple (forward)  det3d/models/bbox_heads/deep_decouple_clear_mg_ohs_head.py:16-301
+  OHS_Multiview (extract_feat + head forward)    det3d/models/detectors/ohs.py:13-92
+Loss, target assignment, box decoding to metric boxes and NMS are out of scope.
+Parity: the attention neck is pinned by tests/golden/attention_*.npz (outputs of the reference's own
+attention.py on CPU, tools/gen_golden_attention.py); necks and head are plain Conv/BN/ReLU stacks checked by shape
+and against a functional re-evaluation from their state_dict.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import Registry, build_from_cfg
+
+NECKS = Registry("neck")
+HEADS = Registry("head")
+DETECTORS = Registry("detector")
+
+
+def _bn2d(norm_cfg, c):
+    cfg = dict(norm_cfg or dict(type="BN", eps=1e-3, momentum=0.01))
+    if cfg.pop("type") != "BN":
+        raise KeyError("the dense necks use BatchNorm2d")
+    return nn.BatchNorm2d(c, **cfg)
+
+
+# ------------------------------------------------------------------------------------------------ necks
+@NECKS.register_module
+class RPN(nn.Module):
+    """Stacks of 3x3 convs per scale + one up/down-sampling branch per scale, concatenated (rpn.py:147-156)."""
+    transposed_unit_deblock = False     # rpn.py:94 uses Conv2d when the up-stride is <= 1, rpnt.py:61 ConvTranspose2d
+
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
+        super().__init__()
+        if not (len(ds_layer_strides) == len(layer_nums) == len(ds_num_filters)):
+            raise AssertionError("layer_nums, ds_layer_strides and ds_num_filters must have one entry per scale")
+        if len(us_num_filters) != len(us_layer_strides):
+            raise AssertionError("us_layer_strides and us_num_filters must match")
+        self._layer_strides, self._upsample_strides = list(ds_layer_strides), list(us_layer_strides)
+        self._upsample_start_idx = len(layer_nums) - len(us_layer_strides)
+        ratios = [us_layer_strides[i] / np.prod(ds_layer_strides[:i + self._upsample_start_idx + 1])
+                  for i in range(len(us_layer_strides))]
+        if any(r != ratios[0] for r in ratios):
+            raise AssertionError("all branches must come out at the same resolution")
+        blocks, deblocks = [], []
+        cin = num_input_features
+        for i, (n, stride, planes) in enumerate(zip(layer_nums, ds_layer_strides, ds_num_filters)):
+            mods = [nn.ZeroPad2d(1), nn.Conv2d(cin, planes, 3, stride=stride, bias=False), _bn2d(norm_cfg, planes),
+                    nn.ReLU()]
+            for _ in range(n):
+                mods += [nn.Conv2d(planes, planes, 3, padding=1, bias=False), _bn2d(norm_cfg, planes), nn.ReLU()]
+            blocks.append(nn.Sequential(*mods))
+            cin = planes
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                us, cout = us_layer_strides[j], us_num_filters[j]
+                if us > 1:
+                    up = nn.ConvTranspose2d(planes, cout, us, stride=us, bias=False)
+                else:
+                    s = int(np.round(1 / us))
+                    conv = nn.ConvTranspose2d if self.transposed_unit_deblock else nn.Conv2d
+                    up = conv(planes, cout, s, stride=s, bias=False)
+                deblocks.append(nn.Sequential(up, _bn2d(norm_cfg, cout), nn.ReLU()))
+        self.blocks, self.deblocks = nn.ModuleList(blocks), nn.ModuleList(deblocks)
+
+    @property
+    def downsample_factor(self):
+        f = np.prod(self._layer_strides)
+        return f / self._upsample_strides[-1] if self._upsample_strides else f
+
+    def forward(self, x):
+        ups = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i >= self._upsample_start_idx:
+                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+        return torch.cat(ups, dim=1) if ups else x
+
+
+@NECKS.register_module
+class RPNT(RPN):
+    transposed_unit_deblock = True
+
+
+class ConvAttentionLayer_Decouple(nn.Module):
+    """Two attention read-outs (semantic / geometric) of one value map: separate q/k 3x3 convs, shared 1x1 v."""
+
+    def __init__(self, input_channels, numhead=1, reduction_ratio=2):
+        super().__init__()
+        c, cr = input_channels, input_channels // reduction_ratio
+        self.q_sem_conv, self.q_geo_conv = nn.Conv2d(c, cr, 3, 1, 1), nn.Conv2d(c, cr, 3, 1, 1)
+        self.k_sem_conv, self.k_geo_conv = nn.Conv2d(c, cr, 3, 1, 1), nn.Conv2d(c, cr, 3, 1, 1)
+        self.v_conv = nn.Conv2d(c, c, 1, 1, 0)
+        self.out_sem_conv, self.out_geo_conv = nn.Conv2d(c, c, 1, 1), nn.Conv2d(c, c, 1, 1)
+        self.sem_norm, self.geo_norm = nn.LayerNorm(c), nn.LayerNorm(c)
+        self.channels, self.numhead = cr, numhead
+        self.head_dim = cr // numhead
+
+    def forward(self, query, key, value, q_pos_emb=None, k_pos_emb=None, need_maps=True):
+        """-> ([tokens[HW_q, B, C]] x2, [attention[B*heads, HW_q, HW_kv]] x2)."""
+        identity = query
+        if q_pos_emb is not None:
+            query = query + q_pos_emb
+        if k_pos_emb is not None:
+            # attention.py:64-65 adds the embedding to `key` in place, and the block passes the SAME tensor as
+            # key and value (attention.py:206) -- so the value path sees the embedding too
+            shared = value is key
+            key = key + k_pos_emb
+            if shared:
+                value = key
+        b, c = identity.shape[:2]
+        hq, wq = query.shape[2:]
+        n = self.numhead
+
+        def tokens(t):                      # [B, n*d, H, W] -> [B*n, H*W, d]
+            bb, cc, hh, ww = t.shape
+            return t.reshape(bb * n, cc // n, hh * ww).transpose(1, 2).contiguous()
+
+        v = tokens(self.v_conv(value))
+        outs, maps = [], []
+        for q_conv, k_conv, o_conv, norm in ((self.q_sem_conv, self.k_sem_conv, self.out_sem_conv, self.sem_norm),
+                                             (self.q_geo_conv, self.k_geo_conv, self.out_geo_conv, self.geo_norm)):
+            q = tokens(q_conv(query) * float(self.head_dim) ** -0.5)
+            k = tokens(k_conv(key))
+            att = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+            r = torch.bmm(att, v)                                                     # [B*n, HW_q, dv]
+            r = r.transpose(1, 2).reshape(b, c, hq, wq)
+            y = identity + o_conv(r)
+            outs.append(norm(y.reshape(b, c, hq * wq).permute(2, 0, 1).contiguous()))
+            maps.append(att if need_maps else None)
+        return outs, maps
+
+
+class FeedFowardLayer(nn.Module):
+    def __init__(self, input_channel, hidden_channel=2048):
+        super().__init__()
+        self.linear1, self.linear2 = nn.Linear(input_channel, hidden_channel), nn.Linear(hidden_channel, input_channel)
+        self.norm = nn.LayerNorm(input_channel)
+        self.activation = nn.ReLU()
+
+    def forward(self, view):
+        return self.norm(view + self.linear2(self.activation(self.linear1(view))))
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """Learned absolute embedding: first half of the channels indexed by column, second half by row."""
+
+    def __init__(self, res, num_pos_feats=384):
+        super().__init__()
+        h, w = res
+        self.row_embed, self.col_embed = nn.Embedding(h, num_pos_feats // 2), nn.Embedding(w, num_pos_feats // 2)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def forward(self, x):
+        h, w = x.shape[-2:]
+        col = self.col_embed.weight[:w].t()[:, None, :].expand(-1, h, -1)      # [C/2, h, w]
+        row = self.row_embed.weight[:h].t()[:, :, None].expand(-1, -1, w)
+        return torch.cat([col, row], 0)[None].expand(x.shape[0], -1, -1, -1)
+
+
+class CrossAttenBlock_Decouple(nn.Module):
+    def __init__(self, input_channels, numhead=1, hidden_channel=2048, reduction_ratio=2):
+        super().__init__()
+        self.cross_atten = ConvAttentionLayer_Decouple(input_channels, numhead, reduction_ratio)
+        self.ffn_sem = FeedFowardLayer(input_channels, hidden_channel)
+        self.ffn_geo = FeedFowardLayer(input_channels, hidden_channel)
+
+    def forward(self, view_1, view_2, pos_emb_1=None, pos_emb_2=None, need_maps=True):
+        b, c, h, w = view_1.shape
+        views, maps = self.cross_atten(view_1, view_2, view_2, pos_emb_1, pos_emb_2, need_maps)
+        outs = [ffn(v).reshape(h, w, b, c).permute(2, 3, 0, 1).contiguous()
+                for ffn, v in zip((self.ffn_sem, self.ffn_geo), views)]
+        return outs, maps
+
+
+@NECKS.register_module
+class Cross_Attention_Decouple(nn.Module):
+    """BEV blocks (queries) attend to RV blocks (keys / values); the two attended block maps are broadcast back
+    over their blocks and added to the BEV map -> (semantic map, geometric map)."""
+
+    def __init__(self, bev_input_channel, rv_input_channel, embed_dim, num_heads, bev_size=(262, 64),
+                 bev_block_res=(16, 16), rv_size=(262, 64), rv_block_res=(16, 16), hidden_channels=1024):
+        super().__init__()
+        self.bev_size, self.rv_size = tuple(bev_size), tuple(rv_size)
+        self.bev_block_res = self.adjust_res(bev_block_res, bev_size)
+        self.rv_block_res = self.adjust_res(rv_block_res, rv_size)
+        self.bev_pos_emb = PositionEmbeddingLearned(self.bev_block_res, embed_dim)
+        self.rv_pos_emb = PositionEmbeddingLearned(self.rv_block_res, embed_dim)
+        self.cross_atten = CrossAttenBlock_Decouple(embed_dim, num_heads, hidden_channels)
+
+    @staticmethod
+    def adjust_res(block_res, size):
+        out = []
+        for n, full in zip(block_res, size):
+            if full % n:
+                raise AssertionError(f"map size {full} must be divisible by the block count {n}")
+            out.append(math.ceil(full / math.ceil(full / n)))
+        return tuple(out)
+
+    def forward(self, x, need_maps=True):
+        bev, rv = x
+        if tuple(bev.shape[-2:]) != self.bev_size or tuple(rv.shape[-2:]) != self.rv_size:
+            raise AssertionError(f"expected BEV {self.bev_size} and RV {self.rv_size} maps, got "
+                                 f"{tuple(bev.shape[-2:])} and {tuple(rv.shape[-2:])}")
+        kb = (bev.shape[-2] // self.bev_block_res[0], bev.shape[-1] // self.bev_block_res[1])
+        kr = (rv.shape[-2] // self.rv_block_res[0], rv.shape[-1] // self.rv_block_res[1])
+        bev_blk, rv_blk = F.avg_pool2d(bev, kb, kb), F.avg_pool2d(rv, kr, kr)
+        outs, maps = self.cross_atten(bev_blk, rv_blk, self.bev_pos_emb(bev_blk), self.rv_pos_emb(rv_blk), need_maps)
+        full = [bev + o.repeat_interleave(kb[0], dim=2).repeat_interleave(kb[1], dim=3) for o in outs]
+        return full, maps
+
+
+# ------------------------------------------------------------------------------------------------- head
+class BoxCoderSpec:
+    """The fields of GroundBox3dCoderAF the head's forward reads (core/bbox/box_coders.py; configs/vista/vista.py:34-40)."""
+
+    def __init__(self, center="soft_argmin", height="bottom_soft_argmin", dim="log_soft_argmin", rotation="vector",
+                 velocity=True, pc_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), kwargs=None, **_):
+        self.center, self.height, self.dim, self.rotation, self.velocity = center, height, dim, rotation, velocity
+        self.pc_range = list(pc_range)
+        self.kwargs = dict(x_range=[-4.5, 4.5], y_range=[-4.5, 4.5], z_range=[-5, 3], xy_bin_num=16, z_bin_num=12,
+                           r_bin_num=12, dim_bin_num=12, dim_range=[-3, 3])
+        self.kwargs.update(kwargs or {})
+
+    @property
+    def n_dim(self):
+        return 2 + 1 + 3 + (2 if self.velocity else 0) + (2 if self.rotation == "vector" else 1)
+
+
+def _branch(cin, mid, cout):
+    return nn.Sequential(nn.Conv2d(cin, mid, 3, 1, 1), nn.BatchNorm2d(mid), nn.ReLU(), nn.Conv2d(mid, cout, 3, 1, 1))
+
+
+class DeepOHSHeadClear_Decouple(nn.Module):
+    """One task group: class scores from the semantic map, box code from the geometric map; binned quantities are
+    read out by soft-argmin over fixed bin centres (deep_decouple_clear_mg_ohs_head.py:127-180)."""
+
+    def __init__(self, box_coder, num_input, num_pred, num_cls, header=True, name="", **kwargs):
+        super().__init__()
+        bc, kw, c = box_coder, box_coder.kwargs, num_input
+        self.box_coder = bc
+        self.mode = kwargs.get("mode", "bev")
+        self.conv_cls = _branch(c, c, num_cls)
+        if bc.center == "direct":
+            self.conv_xy = _branch(c, c, 2)
+        elif bc.center == "soft_argmin":
+            self.conv_xy = _branch(c, c, 2 * kw["xy_bin_num"])
+            bx = torch.linspace(kw["x_range"][0], kw["x_range"][1], kw["xy_bin_num"])
+            by = torch.linspace(kw["y_range"][0], kw["y_range"][1], kw["xy_bin_num"])
+            self.register_buffer("loc_bins", torch.stack([bx, by])[None, :, :, None, None], persistent=False)
+        else:
+            raise NotImplementedError(bc.center)
+        if "direct" in bc.height:
+            self.conv_z = _branch(c, c, 1)
+        elif "soft_argmin" in bc.height:
+            self.conv_z = _branch(c, c, kw["z_bin_num"])
+            self.register_buffer("z_loc_bins", torch.linspace(kw["z_range"][0], kw["z_range"][1],
+                                                               kw["z_bin_num"])[None, :, None, None], persistent=False)
+        else:
+            raise NotImplementedError(bc.height)
+        if "soft_argmin" in bc.dim:
+            self.conv_dim = _branch(c, c, 3 * kw["dim_bin_num"])
+            self.register_buffer("dim_loc_bins", torch.linspace(kw["dim_range"][0], kw["dim_range"][1],
+                                                                 kw["dim_bin_num"])[None, :, None, None], persistent=False)
+        else:
+            self.conv_dim = _branch(c, c, 3)
+        if bc.velocity:
+            self.conv_velo = _branch(c, c, 2)
+        if bc.rotation == "vector":
+            self.conv_r = _branch(c, c, 2)
+        elif bc.rotation == "soft_argmin":
+            self.conv_r = _branch(c, c, kw["r_bin_num"])
+            self.register_buffer("r_loc_bins", torch.linspace(-np.pi, np.pi, kw["r_bin_num"])[None, :, None, None],
+                                 persistent=False)
+        else:
+            self.conv_r = _branch(c, c, 1)
+
+    def forward(self, xs, return_loss=False):
+        x_sem, x_geo = xs
+        bc, kw = self.box_coder, self.box_coder.kwargs
+        last = lambda t: t.permute(0, 2, 3, 1).contiguous()   # noqa: E731
+        cls_preds = last(self.conv_cls(x_sem))
+        xy, z, dim = self.conv_xy(x_geo), self.conv_z(x_geo), self.conv_dim(x_geo)
+        b, _, h, w = xy.shape
+        if bc.center == "soft_argmin":
+            xy = (torch.softmax(xy.view(b, 2, kw["xy_bin_num"], h, w), dim=2) * self.loc_bins).sum(2)
+        if "soft_argmin" in bc.height:
+            z = (torch.softmax(z, dim=1) * self.z_loc_bins).sum(1, keepdim=True)
+        if "soft_argmin" in bc.dim:
+            dim = (torch.softmax(dim.view(b, 3, kw["dim_bin_num"], h, w), dim=2) * self.dim_loc_bins[:, None]).sum(2)
+        xy, z, dim = last(xy), last(z), last(dim)
+        if bc.dim == "direct":
+            dim = F.relu(dim)
+        r = self.conv_r(x_geo)
+        if bc.rotation == "vector":
+            r = F.normalize(r, p=2, dim=1)
+        elif bc.rotation == "soft_argmin":
+            r = (torch.softmax(r, dim=1) * self.r_loc_bins).sum(1, keepdim=True)
+        parts = [xy, z, dim] + ([last(self.conv_velo(x_geo))] if bc.velocity else []) + [last(r)]
+        return {"box_preds": torch.cat(parts, -1), "cls_preds": cls_preds}
+
+
+@HEADS.register_module
+class DeepMultiGroupOHSHeadClear_Decouple(nn.Module):
+    """Shared 3x3 stem per view (384 -> 64) + one DeepOHSHeadClear_Decouple per task group. Forward only."""
+
+    def __init__(self, mode="3d", in_channels=384, norm_cfg=None, tasks=(), weights=(), box_coder=None,
+                 encode_background_as_zeros=True, use_sigmoid_score=True, atten_res=None, name="rpn", **kwargs):
+        super().__init__()
+        self.box_coder = box_coder if box_coder is not None else BoxCoderSpec()
+        self.class_names = [t["class_names"] for t in tasks]
+        self.num_classes = [len(c) for c in self.class_names]
+        self.conv_head = 64
+        stem = lambda: nn.Sequential(nn.Conv2d(in_channels, self.conv_head, 3, 1, 1),   # noqa: E731
+                                     nn.BatchNorm2d(self.conv_head), nn.ReLU())
+        self.sem_conv, self.geo_conv = stem(), stem()
+        self.tasks = nn.ModuleList(
+            DeepOHSHeadClear_Decouple(self.box_coder, self.conv_head, self.box_coder.n_dim,
+                                      n if encode_background_as_zeros else n + 1, header=False, mode=mode)
+            for n in self.num_classes)
+
+    def forward(self, xs, return_loss=False):
+        x_sem, x_geo = self.sem_conv(xs[0]), self.geo_conv(xs[1])
+        return [task((x_sem, x_geo), return_loss) for task in self.tasks]
+
+
+# --------------------------------------------------------------------------------------------- detector
+VISTA_TASKS = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "construction_vehicle"]),
+               dict(num_class=2, class_names=["bus", "trailer"]), dict(num_class=1, class_names=["barrier"]),
+               dict(num_class=2, class_names=["motorcycle", "bicycle"]),
+               dict(num_class=2, class_names=["pedestrian", "traffic_cone"])]
+VISTA_NECK = dict(type="RPNT", layer_nums=[5, 5], ds_layer_strides=[1, 2], ds_num_filters=[128, 256],
+                  us_layer_strides=[1, 2], us_num_filters=[256, 128], num_input_features=640, norm_cfg=None)
+
+
+@DETECTORS.register_module
+class OHS_Multiview(nn.Module):
+    """reader -> MultiViewBackbone -> BEV neck, RV neck -> cross-view attention -> head (ohs.py:57-66,83-85).
+    Module names follow the reference detector (reader, backbone, neck, rv_neck, ca_neck, bbox_head)."""
+
+    def __init__(self, reader=None, backbone=None, neck=None, bbox_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__()
+        from . import models  # noqa: F401  (registers reader / backbones)
+        from .registry import BACKBONES, READERS
+        neck = dict(neck or VISTA_NECK)
+        self.reader = build_from_cfg(reader or dict(type="VoxelFeatureExtractorV3", num_input_features=5), READERS)
+        self.backbone = build_from_cfg(backbone or dict(type="MultiViewBackbone", num_input_features=5, ds_factor=8),
+                                       BACKBONES)
+        self.neck = build_from_cfg(neck, NECKS)
+        self.rv_neck = build_from_cfg(neck, NECKS)
+        self.ca_neck = build_from_cfg(dict(type="Cross_Attention_Decouple", bev_input_channel=384, rv_input_channel=384,
+                                           embed_dim=384, num_heads=1, bev_size=(160, 160), bev_block_res=(40, 40),
+                                           rv_size=(160, 12), rv_block_res=(40, 12), hidden_channels=512), NECKS)
+        self.bbox_head = build_from_cfg(bbox_head or dict(type="DeepMultiGroupOHSHeadClear_Decouple", mode="bev",
+                                                          in_channels=384, tasks=VISTA_TASKS), HEADS)
+
+    def dense_tail(self, x_bev, x_rv, need_maps=False):
+        """(BEV map, RV map) of the backbone -> list of per-task {"box_preds", "cls_preds"}."""
+        xs, _ = self.ca_neck((self.neck(x_bev), self.rv_neck(x_rv)), need_maps=need_maps)
+        return self.bbox_head(xs, False)
+
+    def forward(self, example, return_loss=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError("losses / target assignment are outside this path (SURVEY 8f)")
+        feats = self.reader(example["voxels"], example["num_points"])
+        x_bev, x_rv = self.backbone(feats, example["coordinates"], len(example["num_voxels"]), example["shape"][0])
+        return self.dense_tail(x_bev, x_rv)
