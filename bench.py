@@ -251,6 +251,7 @@ def main():
         dt = float(t.item())
     total_frames = world * a.batch * a.steps
     sweeps = 40 if a.geometry == "STRESS" else 10
+    cfg_name = "configs[2]" if a.full_net else "configs[3]" if a.geometry == "STRESS" else "configs[1]"
     res = {
         "metric": (f"backbone frames/sec (voxelize + mean VFE + {a.backbone} forward)" if not a.full_net else
                    "full-net frames/sec (voxelize + mean VFE + MultiViewBackbone + necks + cross-view attention + "
@@ -261,7 +262,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{a.geometry} {sweeps}-sweep synthetic nuScenes-shaped frames, sparse_shape "
                                f"{[grid[2] + 1, grid[1], grid[0]]}, batch {a.batch}/GPU, inference, "
-                               "inputs resident in HBM (BASELINE.json configs[1])",
+                               f"inputs resident in HBM (BASELINE.json {cfg_name})",
                    "frames_per_gpu": a.batch, "points_per_frame": int(np.mean([f.shape[0] for f in frames])),
                    "parallelism": f"frame-sharded x{world}"},
     }
