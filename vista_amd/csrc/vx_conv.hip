@@ -35,6 +35,7 @@ struct ConvArgs {
   float* out;           // [n_out][cout]
   int dtype;            // VX_F32 | VX_BF16 (element type of in / w / residual / out)
   const int* perm;      // optional: tile row j computes output row perm[j] (table is pre-permuted)
+  const void* zero;     // 512 zero bytes in device memory: what a missing neighbour reads
 };
 
 // bijective XCD-aware remap: consecutive tiles (which share gathered neighbours) run on one XCD
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
                NW * kKSlots * 32;
   const T* in = reinterpret_cast<const T*>(a.in);
   const T* wgt = reinterpret_cast<const T*>(a.w);
-  const T* zero = reinterpret_cast<const T*>(vx_zero_row);
+  const T* zero = reinterpret_cast<const T*>(a.zero);
 
   const int r = lane & 31, h = lane >> 5;
   const long long tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -371,30 +372,31 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
     }
   };
 
+  // The loop body is straight-line on purpose: every trip issues the same loads and stores (the last trip
+  // re-fetches its own chunk, a wave that skips a chunk stages zero rows for it), so the compiler can place
+  // exact counted waits. With the prefetch under `if`s it merged the two paths' wait state and drained the
+  // W loads (vmcnt(0)) before issuing the gathers, exposing one L2 round trip per chunk.
   int c = next_chunk(-1);
   int buf = 0;
   if (c < nchunks) {
     load_w(c);
-    if (chunk_used(wmask, c)) {
-      load_a(c);
-      store_a();
-    }
+    load_a(c);
+    store_a();
     store_w(0);
   }
   __syncthreads();
   while (c < nchunks) {
     // chunk c is staged (sA, sW[buf]); prefetch chunk cn into registers while its MFMAs run
     const int cn = next_chunk(c);
-    const bool more = cn < nchunks;
-    const bool more_a = more && chunk_used(wmask, cn);
+    const int cl = cn < nchunks ? cn : c;
     VX_STAMP_T(t1);
-    if (more) load_w(cn);
-    if (more_a) load_a(cn);
+    load_w(cl);
+    load_a(cl);
     VX_STAMP_T(t2);
     if (chunk_used(wmask, c)) mfma_chunk(buf);
     VX_STAMP_T(t3);
-    if (more_a) store_a();
-    if (more) store_w(buf ^ 1);
+    store_a();
+    store_w(buf ^ 1);
     VX_STAMP_T(t4);
     __syncthreads();
     VX_STAMP_T(t5);
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
   int* sMask = reinterpret_cast<int*>(smem_raw + 2 * COUT_PAD * kRowPadD) + NW * kKSlots * 32;
   const T* in = reinterpret_cast<const T*>(a.in);
   const T* wgt = reinterpret_cast<const T*>(a.w);
-  const T* zero = reinterpret_cast<const T*>(vx_zero_row);
+  const T* zero = reinterpret_cast<const T*>(a.zero);
 
   const int r = lane & 31, h = lane >> 5;
   const long long tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -541,22 +543,21 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
       Elem<T>::template mma<NT>(ra[j], bv, acc);
     }
   };
-  // one pipeline step: chunk c is in `cur` + sW[buf]; prefetch chunk cn into `nxt` + sW[buf^1]
+  // one pipeline step: chunk c is in `cur` + sW[buf]; prefetch chunk cn into `nxt` + sW[buf^1].
+  // Straight-line like spconv_w8's loop (unconditional loads/stores; the last step re-fetches its own chunk).
   auto step = [&](int c, int cn, int buf, const f32x4(&cur)[8], f32x4(&nxt)[8]) {
-    const bool more = cn < nchunks;
-    if (more) {
-      load_w(cn);
-      if (chunk_used(wmask, cn)) load_a(cn, nxt);
-    }
+    const int cl = cn < nchunks ? cn : c;
+    load_w(cl);
+    load_a(cl, nxt);
     if (chunk_used(wmask, c)) mfma_chunk(buf, cur);
-    if (more) store_w(buf ^ 1);
+    store_w(buf ^ 1);
     __syncthreads();
   };
 
   int c = next_chunk(-1);
   if (c < nchunks) {
     load_w(c);
-    if (chunk_used(wmask, c)) load_a(c, r0);
+    load_a(c, r0);
     store_w(0);
   }
   __syncthreads();
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64) void spconv_f32_ws(ConvArgs a, const f32x4* __r
       const int P = c * CK + h * (CK / 2) + 4 * q;
       const int g = P / CIN, ch = P % CIN;
       const int idx = g < kKSlots ? sIdx[g * 32 + r] : -1;
-      const float* src = idx >= 0 ? in + (long long)idx * CIN + ch : vx_zero_row;
+      const float* src = idx >= 0 ? in + (long long)idx * CIN + ch : reinterpret_cast<const float*>(a.zero);
       dst[q] = *reinterpret_cast<const f32x4*>(src);
     }
   };
@@ -839,6 +840,24 @@ int32_t dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.cin <= 64) return dispatch_cout<64>(a, s);
   return dispatch_cout<128>(a, s);
 }
+// Device address of vx_zero_row on the current device (passed to the kernels as an argument: taking the
+// symbol's address inside the kernel costs a GOT load per use in the main loop).
+int32_t zero_row_address(const void** out) {
+  static const void* cache[64] = {};
+  int dev = 0;
+  VX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) {
+    vx_set_error("zero_row_address: device index %d out of range", dev);
+    return VX_ERR_ARG;
+  }
+  if (!cache[dev]) {
+    void* p = nullptr;
+    VX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(vx_zero_row)));
+    cache[dev] = p;
+  }
+  *out = cache[dev];
+  return VX_OK;
+}
 }  // namespace
 
 extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
@@ -875,6 +894,7 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
   a.out = (float*)d_out;
   a.dtype = dtype;
   a.perm = d_perm;
+  if (int32_t rc = zero_row_address(&a.zero)) return rc;
   if (d_wpack && dtype == VX_F32 && cout <= 128 && kvol <= kKSlots &&
       (reinterpret_cast<uintptr_t>(d_in) & 15) == 0) {
     const int32_t rc = dispatch_ws(a, d_wpack, (hipStream_t)stream);
@@ -928,5 +948,6 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.out = (float*)d_din;
   a.dtype = dtype;
   a.perm = nullptr;
+  if (int32_t rc = zero_row_address(&a.zero)) return rc;
   return dispatch(a, (hipStream_t)stream);
 }
