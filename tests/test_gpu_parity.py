@@ -115,7 +115,11 @@ def test_voxelization_double_flip_stage(dev):
         clouds[f"{key}_points"] = q
     stage = Voxelization(cfg=dict(range=m["range"], voxel_size=m["voxel_size"], max_points_in_voxel=m["max_points"],
                                   max_voxel_num=m["max_voxels"], double_flip=True))
-    res, _ = stage(dict(lidar={k: torch.from_numpy(v).to(dev) for k, v in clouds.items()}, mode="val"), None)
+    from vista_amd.voxel import DoubleFlip
+    res, _ = DoubleFlip()(dict(lidar=dict(points=torch.from_numpy(pts).to(dev)), mode="val"), None)   # GPU flips
+    for k, v in clouds.items():
+        np.testing.assert_array_equal(res["lidar"][k].cpu().numpy(), v)
+    res, _ = stage(res, None)
     for key in ("", "yflip_", "xflip_", "double_flip_"):
         vd = res["lidar"][f"{key}voxels"]
         v, c, n = ov.voxelize(clouds[f"{key}points"], m["voxel_size"], m["range"], m["max_points"], m["max_voxels"])

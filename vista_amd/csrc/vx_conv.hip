@@ -9,6 +9,8 @@
 //   spconv_f32_w8      the hot path (cin in {8,16,32,64,128}, KRSC weights, kvol <= 32)
 //   spconv_f32_generic any cin <= 128 / strided weights (first layer cin=5): simple, LDS staged
 // dgrad runs on the same kernels with the roles of in/out swapped and a transposed weight copy.
+#include <atomic>
+
 #include "vx_common.h"
 
 namespace {
@@ -843,19 +845,21 @@ int32_t dispatch(const ConvArgs& a, hipStream_t s) {
 // Device address of vx_zero_row on the current device (passed to the kernels as an argument: taking the
 // symbol's address inside the kernel costs a GOT load per use in the main loop).
 int32_t zero_row_address(const void** out) {
-  static const void* cache[64] = {};
+  static std::atomic<const void*> cache[64];     // per device; a racing first call stores the same value
   int dev = 0;
   VX_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) {
     vx_set_error("zero_row_address: device index %d out of range", dev);
     return VX_ERR_ARG;
   }
-  if (!cache[dev]) {
-    void* p = nullptr;
-    VX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(vx_zero_row)));
-    cache[dev] = p;
+  const void* p = cache[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* q = nullptr;
+    VX_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(vx_zero_row)));
+    cache[dev].store(q, std::memory_order_release);
+    p = q;
   }
-  *out = cache[dev];
+  *out = p;
   return VX_OK;
 }
 }  // namespace

@@ -114,6 +114,21 @@ class Voxelization:
         return res, info
 
 
+@PIPELINES.register_module
+class DoubleFlip:
+    """Test-time augmentation stage (test_aug.py:52-77) on the GPU: adds the y-, x- and xy-flipped copies of
+    res["lidar"]["points"]; with cfg.double_flip the Voxelization stage then voxelizes all four in one batch
+    (one frame's TTA = a batch of 4 through the backbone, in the order formating.py:98 returns them)."""
+
+    def __call__(self, res, info):
+        pts = res["lidar"]["points"]
+        for key, cols in (("yflip_points", [1]), ("xflip_points", [0]), ("double_flip_points", [0, 1])):
+            q = pts.clone()
+            q[:, cols] = -q[:, cols]
+            res["lidar"][key] = q
+        return res, info
+
+
 def collate_voxels(frames):
     """frames: list of per-frame dicts from Voxelization -> batch dict with coordinates [sum M, 4] (b,z,y,x)."""
     coords = [torch.nn.functional.pad(f["coordinates"], (1, 0), value=i) for i, f in enumerate(frames)]
