@@ -37,6 +37,9 @@ extern "C" {
 
 /* epilogue flags of vx_spconv_fwd */
 #define VX_EPI_RELU 1
+/* kernel choice of vx_spconv_fwd: fp32 layers with cin in {16,32,64} and cout <= 128 run the per-offset
+   compaction kernel unless this flag asks for the row-stationary kernels (A/B timing, tests) */
+#define VX_CONV_NO_COMPACT 0x100
 
 int32_t vx_version(void);
 const char* vx_last_error(void);

@@ -203,9 +203,11 @@ def test_rulebook_empty(dev):
 CH = [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 32), (7, 9)]
 
 
+@pytest.mark.parametrize("compact", [True, False])
 @pytest.mark.parametrize("cin,cout", CH)
-def test_conv_fwd_subm_vs_oracle(cin, cout, dev):
-    """fp32 tolerance: 1e-4 relative (north_star); observed error is summation-order only."""
+def test_conv_fwd_subm_vs_oracle(cin, cout, compact, dev):
+    """fp32 tolerance: 1e-4 relative (north_star); observed error is summation-order only. compact=True is the
+    library's default choice (per-offset compaction kernel where eligible), False forces the row-stationary kernels."""
     from oracle import spconv_oracle as so
     from vista_amd import ops
     rng = np.random.default_rng(cin * 1000 + cout)
@@ -219,13 +221,14 @@ def test_conv_fwd_subm_vs_oracle(cin, cout, dev):
     ref = so.conv_fwd(feat, w, nbr, bias)
     rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
     got = ops.conv_fwd(torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev), rb,
-                       bias=torch.from_numpy(bias).to(dev)).cpu().numpy()
+                       bias=torch.from_numpy(bias).to(dev), compact=compact).cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 1e-4 * scale, np.abs(got - ref).max() / scale
 
 
+@pytest.mark.parametrize("compact", [True, False])
 @pytest.mark.parametrize("ks,st,pd", GEOMS)
-def test_conv_fwd_strided_and_epilogue(ks, st, pd, dev):
+def test_conv_fwd_strided_and_epilogue(ks, st, pd, compact, dev):
     from oracle import spconv_oracle as so
     from vista_amd import ops
     rng = np.random.default_rng(3)
@@ -242,12 +245,12 @@ def test_conv_fwd_strided_and_epilogue(ks, st, pd, dev):
     rb = ops.rulebook_conv(torch.from_numpy(coords).to(dev), 2, shape, ks, st, pd)
     got = ops.conv_fwd(torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev), rb,
                        scale=torch.from_numpy(sc).to(dev), shift=torch.from_numpy(sh).to(dev),
-                       residual=torch.from_numpy(res).to(dev), relu=True).cpu().numpy()
+                       residual=torch.from_numpy(res).to(dev), relu=True, compact=compact).cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("subm", [True, False])
-@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 32), (64, 64), (128, 128), (128, 32)])
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 32), (32, 16), (64, 64), (128, 64), (128, 128), (128, 32)])
 def test_conv_grads_vs_oracle(subm, cin, cout, dev):
     from oracle import spconv_oracle as so
     from vista_amd import ops
@@ -483,8 +486,8 @@ def test_mask_sorted_rows_bitwise_identical(dev):
         x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).to(dev).to(dt)
         w = torch.from_numpy((rng.normal(size=(cout, 3, 3, 3, cin)) / 30).astype(np.float32)).to(dev).to(dt)
         res = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).to(dev).to(dt)
-        a = ops.conv_fwd(x, w, rb, residual=res, relu=True, sort_rows=True)
-        b = ops.conv_fwd(x, w, rb, residual=res, relu=True, sort_rows=False)
+        a = ops.conv_fwd(x, w, rb, residual=res, relu=True, sort_rows=True, compact=False)
+        b = ops.conv_fwd(x, w, rb, residual=res, relu=True, sort_rows=False, compact=False)
         assert torch.equal(a, b)
 
 
@@ -507,7 +510,7 @@ def test_conv_fwd_streaming_w_kernel(cin, cout, dev):
     x, wt, b = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev)
     wp = ops.pack_weight(wt)
     got = ops.conv_fwd(x, wt, rb, bias=b, relu=False, wpack=wp, sort_rows=True)
-    base = ops.conv_fwd(x, wt, rb, bias=b, relu=False)
+    base = ops.conv_fwd(x, wt, rb, bias=b, relu=False, compact=False)
     assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     assert torch.equal(got, base)
 

@@ -11,6 +11,7 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 use_ws = len(sys.argv) > 2 and sys.argv[2] == "ws"
 sort_rows = len(sys.argv) > 3 and sys.argv[3] == "sort"
+compact = not (len(sys.argv) > 2 and sys.argv[2] == "nocb")
 dev = torch.device("cuda:0")
 rg, vs, T, mv = GEOMETRIES["FHD"]
 gen = VoxelGenerator(vs, rg, T, mv)
@@ -35,14 +36,19 @@ for name, cin, cout, rb in stages:
     pairs = int((rb.nbr >= 0).sum().item())
     wp = ops.pack_weight(w) if use_ws else None
     for _ in range(2):
-        ops.conv_fwd(x, w, rb, wpack=wp, sort_rows=sort_rows)
+        ops.conv_fwd(x, w, rb, wpack=wp, sort_rows=sort_rows, compact=compact)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        ops.conv_fwd(x, w, rb, wpack=wp, sort_rows=sort_rows)
+        ops.conv_fwd(x, w, rb, wpack=wp, sort_rows=sort_rows, compact=compact)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    if compact:
+        ref = ops.conv_fwd(x, w, rb, compact=False)
+        got = ops.conv_fwd(x, w, rb, compact=True)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        name = f"{name}[err {err:.1e}]"
     fl = 2.0 * pairs * cin * cout
     print(f"{name:6s} {cin:3d}->{cout:3d} n_out={rb.n_out:8d} pairs={pairs:9d} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  "
           f"gather {pairs * cin * x.element_size() / ms / 1e6:7.1f} GB/s")

@@ -97,3 +97,26 @@ for stage in range(4):
         ks, st, pd = convs[stage]
         cur, _, shp = so.rulebook_conv(cur, shp, ks, st, pd)
         shp = list(shp)
+
+
+def half64_model(nbr, name):
+    """Design-B variant: each 64-row half of a 128-row tile compacts its own pairs per offset into groups of 32."""
+    K, N = nbr.shape
+    act = nbr >= 0
+    pad = (-N) % 64
+    p = np.pad(act, ((0, 0), (0, pad))).reshape(K, -1, 64).sum(2)
+    slots = (-(-p // 32)) * 32
+    print(f"{name}: half64 compaction: MFMA row slots / pairs = {slots.sum() / act.sum():.2f} "
+          f"(32-row groups today: {(np.pad(act, ((0, 0), (0, (-N) % 32))).reshape(K, -1, 32).any(2).sum() * 32) / act.sum():.2f})")
+
+
+print("per-64-row-half compaction")
+cur, shp = coords, shape
+for stage in range(4):
+    nbr = np.asarray(so.rulebook_subm(np.ascontiguousarray(cur), shp, (3, 3, 3)))
+    half64_model(nbr, f"stage{stage} subm")
+    if stage < 3:
+        ks, st, pd = convs[stage]
+        cur2, nbrc, shp2 = so.rulebook_conv(cur, shp, ks, st, pd)
+        half64_model(np.asarray(nbrc), f"stage{stage}->{stage + 1} strided conv")
+        cur, shp = cur2, list(shp2)

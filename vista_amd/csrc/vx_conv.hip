@@ -596,6 +596,225 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-offset compaction kernel (fp32, Cout <= 64): the output-stationary kernels above spend an MFMA row
+// on every (row, offset) slot of an active 32-row group, present or not -- 42 % (C=64) to 66 % (C=16) of
+// their matrix work at the FHD stages, and far more in the strided convs. Here a 4-wave workgroup owns
+// 128 output rows whose accumulators live in LDS; for each kernel offset every wave compacts the tile's
+// present (row, input) pairs in registers (two ballots + ds_permute, no LDS list, no extra barrier),
+// wave g takes pairs [32g, 32g+32), gathers their input rows straight into MFMA fragment layout,
+// multiplies with W_k (LDS, double buffered: one barrier per offset) and adds its 32 x Cout result into
+// the LDS accumulator rows of those pairs. Within one offset an output row belongs to exactly one pair,
+// hence one wave; offsets are separated by the barrier: plain in-order sums, bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+#ifndef VX_CB_WAVES
+#define VX_CB_WAVES 4      // waves (= 32-row groups) per workgroup of the compaction kernel
+#endif
+#ifndef VX_CB_WAVES_64
+#define VX_CB_WAVES_64 8   // Cin = 64, Cout >= 64: W_k is 16 KB per offset, a 256-row tile halves its re-reads
+#endif
+
+template <int CIN, int COUT_PAD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(ConvArgs a) {
+  constexpr int kCbRows = 32 * WAVES, kCbThreads = 64 * WAVES;
+  constexpr int NE = kCbRows / 64;                   // neighbour entries per lane
+  constexpr int NT = COUT_PAD / 32;
+  constexpr int QH = CIN / 8;                        // 16-byte quads per lane half (CIN/2 floats)
+  constexpr int W_ROW = CIN * 4 + 16;                // padded W row (bytes): conflict-free ds_read_b128
+  constexpr int W_Q = COUT_PAD * CIN / 4;            // quads of one offset's weights
+  constexpr int W_LD = (W_Q + kCbThreads - 1) / kCbThreads;
+  constexpr int ACC_LD = COUT_PAD + 4;               // +16 B per row: rows 16 apart share a bank group, not neighbours
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sAcc = reinterpret_cast<float*>(smem_raw);                       // [(R + 1)][ACC_LD], row R = dump
+  char* sWb = smem_raw + (kCbRows + 1) * ACC_LD * 4;                      // 2 x [COUT_PAD][W_ROW]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
+  const int col0 = blockIdx.y * COUT_PAD;
+  const float* in = a.in;
+  const float* zero = reinterpret_cast<const float*>(a.zero);
+
+  for (int e = threadIdx.x; e < (kCbRows + 1) * ACC_LD; e += kCbThreads) sAcc[e] = 0.0f;
+
+  // neighbour entries of offset ks for tile rows lane, lane + 64, ... (-1 past the end / absent)
+  auto load_nbr = [&](int ks, int (&e)[NE]) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) e[j] = -1;
+    if (ks < a.kvol) {
+      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
+      const int* t = a.nbr + (long long)krow * a.ld + row0;
+#pragma unroll
+      for (int j = 0; j < NE; ++j)
+        if (row0 + lane + 64 * j < a.n_out) e[j] = t[lane + 64 * j];
+    }
+  };
+  // compaction of the tile's entries; this wave keeps pairs [32*wave, 32*wave + 32):
+  // lanes 0..31 receive (input row + 1, local output row + 1) of their slot, 0 = empty slot
+  auto my_group = [&](const int (&e)[NE], int& idx_p1, int& row_p1) {
+    int base = -32 * wave, ii = 0, qq = 0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const unsigned long long m = __ballot(e[j] >= 0);
+      const int d = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+      const bool p = e[j] >= 0 && d >= 0 && d < 32;
+      // ds_permute pushes to lane (addr / 4); lanes that push nothing aim a zero at lanes 32..63
+      const int ad = (p ? d : 32 + (lane & 31)) << 2;
+      ii |= __builtin_amdgcn_ds_permute(ad, p ? e[j] + 1 : 0);
+      qq |= __builtin_amdgcn_ds_permute(ad, p ? lane + 64 * j + 1 : 0);
+      base += __popcll(m);
+    }
+    idx_p1 = lane < 32 ? ii : 0;
+    row_p1 = lane < 32 ? qq : 0;
+    return base + 32 * wave;       // pairs of this offset in the tile
+  };
+  auto load_a = [&](int idx_p1, f32x4(&dst)[QH]) {
+    const int idx = __shfl(idx_p1, r, 64) - 1;
+    const float* src = idx >= 0 ? in + (long long)idx * CIN + h * (CIN / 2) : zero;
+#pragma unroll
+    for (int q = 0; q < QH; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+  };
+  f32x4 rw[W_LD];
+  auto load_w = [&](int ks) {
+    const int kk = ks < a.kvol ? ks : a.kvol - 1;
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kCbThreads + (int)threadIdx.x;
+      const int oc = e / (CIN / 4), q = e % (CIN / 4);
+      const int goc = col0 + oc;
+      const bool ok = e < W_Q && goc < a.cout;
+      const float* src = ok ? a.w + ((long long)goc * a.kvol + kk) * CIN + 4 * q : zero;
+      rw[t] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_w = [&](int buf) {
+    char* sW = sWb + buf * COUT_PAD * W_ROW;
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kCbThreads + (int)threadIdx.x;
+      const int oc = e / (CIN / 4), q = e % (CIN / 4);
+      if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
+    }
+  };
+  // 32 pairs x Cout, computed TRANSPOSED (W fragment as the A operand, gathered rows as B): lane (r, h) then
+  // holds Cout values 8q + 4h + {0..3} of pair slot r, i.e. 16 contiguous bytes of that pair's accumulator row:
+  // the += into LDS is 4 ds_read_b128 + 4 ds_write_b128 per 32 channels
+  auto mfma_group = [&](int buf, const f32x4(&ra)[QH], int row_p1) {
+    f32x16 d[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[t][i] = 0.0f;
+    const char* pb = sWb + buf * COUT_PAD * W_ROW + r * W_ROW + h * (CIN * 2);
+#pragma unroll
+    for (int j = 0; j < QH; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + t * 32 * W_ROW + 16 * j);
+        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, ra[j].x, d[t], 0, 0, 0);
+        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, ra[j].y, d[t], 0, 0, 0);
+        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, ra[j].z, d[t], 0, 0, 0);
+        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, ra[j].w, d[t], 0, 0, 0);
+      }
+    }
+    const int rp = __shfl(row_p1, r, 64);
+    float* arow = sAcc + (rp > 0 ? rp - 1 : kCbRows) * ACC_LD + 4 * h;   // empty slots add zeros to the dump row
+    // no other wave touches this row during this offset: plain read-add-write (ds_add_f32 measured 4-5x
+    // slower for the whole kernel: LDS float atomics do not run at the ds_read / ds_write rate)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4* dst = reinterpret_cast<f32x4*>(arow + t * 32 + 8 * q);
+        f32x4 v = *dst;
+        v.x += d[t][4 * q + 0];
+        v.y += d[t][4 * q + 1];
+        v.z += d[t][4 * q + 2];
+        v.w += d[t][4 * q + 3];
+        *dst = v;
+      }
+  };
+
+  int en[NE], fn[NE];                 // entries of offsets k+1 (en) and k+2 (fn), prefetched
+  int idxA, rowA, idxB, rowB;
+  f32x4 raA[QH], raB[QH];
+  load_nbr(0, en);
+  load_nbr(1, fn);
+  int cntA = my_group(en, idxA, rowA);
+  load_w(0);
+  load_a(idxA, raA);
+  store_w(0);
+  __syncthreads();
+  // one trip = two offsets (ping-pong register sets); straight-line bodies, clamped loads past the end
+  auto step = [&](int k, int buf, int cnt_cur, const f32x4(&cur)[QH], int row_cur, int& cnt_nxt, f32x4(&nxt)[QH],
+                  int& idx_nxt, int& row_nxt) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) en[j] = fn[j];
+    load_nbr(k + 2, fn);
+    cnt_nxt = my_group(en, idx_nxt, row_nxt);
+    load_w(k + 1);
+    load_a(idx_nxt, nxt);
+    if (32 * wave < cnt_cur) mfma_group(buf, cur, row_cur);
+    store_w(buf ^ 1);
+    __syncthreads();
+  };
+  int cntB = 0;
+  for (int k = 0; k < a.kvol; k += 2) {
+    step(k, 0, cntA, raA, rowA, cntB, raB, idxB, rowB);
+    if (k + 1 >= a.kvol) break;
+    step(k + 1, 1, cntB, raB, rowB, cntA, raA, idxA, rowA);
+  }
+  __syncthreads();
+
+  // ---- epilogue: bias, per-channel affine (folded BatchNorm), residual, ReLU; coalesced rows ----
+  constexpr int CQ = COUT_PAD / 4;
+  for (int e = threadIdx.x; e < kCbRows * CQ; e += kCbThreads) {
+    const int rr = e / CQ, c = col0 + 4 * (e % CQ);
+    const long long row = row0 + rr;
+    if (row >= a.n_out) continue;
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(sAcc + rr * ACC_LD + 4 * (e % CQ));
+    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = c + j;
+      if (col >= a.cout) continue;
+      float v = vv[j] + (a.bias ? a.bias[col] : 0.0f);
+      if (a.scale || a.shift) v = v * (a.scale ? a.scale[col] : 1.0f) + (a.shift ? a.shift[col] : 0.0f);
+      if (a.residual) v += a.residual[row * a.cout + col];
+      if (a.relu) v = fmaxf(v, 0.0f);
+      a.out[row * a.cout + col] = v;
+    }
+  }
+}
+
+template <int CIN, int COUT_PAD, int WAVES>
+int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
+  constexpr int R = 32 * WAVES;
+  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * 4 + 16);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = spconv_cb<CIN, COUT_PAD, WAVES>;
+  VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
+  kern<<<grid, 64 * WAVES, lds, stream>>>(a);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+// 1 = not eligible
+int32_t dispatch_cb(const ConvArgs& a, hipStream_t s) {
+  if (a.dtype != VX_F32 || a.perm || (reinterpret_cast<uintptr_t>(a.in) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15) ||
+      a.w_si != 1 || a.w_sk != a.cin || a.w_so != (long long)a.kvol * a.cin)
+    return 1;
+  const bool wide = a.cout > 32;       // Cout > 64 is tiled over blockIdx.y in slices of 64
+  if (a.cout > 128) return 1;
+  switch (a.cin) {
+    case 16: return wide ? launch_cb<16, 64, VX_CB_WAVES>(a, s) : launch_cb<16, 32, VX_CB_WAVES>(a, s);
+    case 32: return wide ? launch_cb<32, 64, VX_CB_WAVES>(a, s) : launch_cb<32, 32, VX_CB_WAVES>(a, s);
+    case 64: return wide ? launch_cb<64, 64, VX_CB_WAVES_64>(a, s) : launch_cb<64, 32, VX_CB_WAVES>(a, s);
+    default: return 1;
+  }
+}
+
 template <typename T, int CIN, int COUT_PAD>
 int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   // LDS-staged gather where a chunk carries enough MFMA work to hide its LDS round trip
@@ -899,6 +1118,10 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
   a.dtype = dtype;
   a.perm = d_perm;
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
+  if (!(flags & VX_CONV_NO_COMPACT)) {   // fp32, Cin in {16,32,64}, Cout <= 128: per-offset compaction kernel
+    const int32_t rc = dispatch_cb(a, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   if (d_wpack && dtype == VX_F32 && cout <= 128 && kvol <= kKSlots &&
       (reinterpret_cast<uintptr_t>(d_in) & 15) == 0) {
     const int32_t rc = dispatch_ws(a, d_wpack, (hipStream_t)stream);
@@ -953,5 +1176,9 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.dtype = dtype;
   a.perm = nullptr;
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
+  {
+    const int32_t rc = dispatch_cb(a, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   return dispatch(a, (hipStream_t)stream);
 }

@@ -313,12 +313,13 @@ def pack_weight(weight):
 
 
 def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False,
-             sort_rows=False, wpack=None):
+             sort_rows=False, wpack=None, compact=True):
     """features [n_in,Cin], weight [Cout,kz,ky,kx,Cin] (KRSC) -> [n_out,Cout]; fused epilogue
     relu?((acc + bias) * scale + shift + residual). sort_rows: run on the rulebook's mask-sorted
     row order (same bits out); wpack: packed weight copy -> barrier-free streaming-W kernel (fp32).
     Both are OFF by default: measured on MI355X they only pay together, on the
-    sparse strided layers, and the sort costs what they save."""
+    sparse strided layers, and the sort costs what they save. compact=False forces the row-stationary
+    kernels where the library would pick the per-offset compaction kernel (fp32, Cin <= 64)."""
     _need_gpu(features, "features")
     if features.dtype not in _DT:
         raise ValueError(f"unsupported feature dtype {features.dtype}")
@@ -340,13 +341,16 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
         if residual.shape != out.shape or residual.dtype != out.dtype:
             raise ValueError("residual must match the output shape and dtype")
     nbr, perm = rb.nbr, None
+    if wpack is not None or sort_rows:
+        compact = False
     if sort_rows and rb.n_out >= 4096 and rb.kvol > 1:
         nbr, perm = rb.sorted_table()
     with torch.cuda.device(features.device), _Timed("conv", cin=cin, cout=cout, kvol=rb.kvol, rb=rb,
                                                    esize=features.element_size()):
         rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(nbr),
                                    max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
-                                   _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(perm), _ptr(wpack),
+                                   _ptr(residual), (L.VX_EPI_RELU if relu else 0) | (0 if compact else L.VX_CONV_NO_COMPACT),
+                                   _ptr(perm), _ptr(wpack),
                                    _ptr(out), _DT[features.dtype], _stream())
     L.check(rc, "vx_spconv_fwd")
     return out
