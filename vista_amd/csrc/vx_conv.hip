@@ -610,18 +610,27 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
 #ifndef VX_CB_WAVES
 #define VX_CB_WAVES 4      // waves (= 32-row groups) per workgroup of the compaction kernel
 #endif
+#ifndef VX_CB_BF16_128
+#define VX_CB_BF16_128 0
+#endif
+#ifndef VX_CB_BF16
+#define VX_CB_BF16 1
+#endif
 #ifndef VX_CB_WAVES_64
 #define VX_CB_WAVES_64 8   // Cin = 64, Cout >= 64: W_k is 16 KB per offset, a 256-row tile halves its re-reads
 #endif
 
-template <int CIN, int COUT_PAD, int WAVES>
+template <typename T, int CIN, int COUT_PAD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(ConvArgs a) {
   constexpr int kCbRows = 32 * WAVES, kCbThreads = 64 * WAVES;
   constexpr int NE = kCbRows / 64;                   // neighbour entries per lane
   constexpr int NT = COUT_PAD / 32;
-  constexpr int QH = CIN / 8;                        // 16-byte quads per lane half (CIN/2 floats)
-  constexpr int W_ROW = CIN * 4 + 16;                // padded W row (bytes): conflict-free ds_read_b128
-  constexpr int W_Q = COUT_PAD * CIN / 4;            // quads of one offset's weights
+  constexpr int EB = (int)sizeof(T);
+  constexpr int QR = CIN * EB / 16;                  // 16-byte quads per row
+  constexpr int QH = QR / 2;                         // quads per lane half (half a row)
+  static_assert(QH >= 1, "a lane half needs at least one 16-byte quad");
+  constexpr int W_ROW = CIN * EB + 16;               // padded W row (bytes): conflict-free ds_read_b128
+  constexpr int W_Q = COUT_PAD * QR;                 // quads of one offset's weights
   constexpr int W_LD = (W_Q + kCbThreads - 1) / kCbThreads;
   constexpr int ACC_LD = COUT_PAD + 4;               // +16 B per row: rows 16 apart share a bank group, not neighbours
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -632,8 +641,9 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
   const int r = lane & 31, h = lane >> 5;
   const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
   const int col0 = blockIdx.y * COUT_PAD;
-  const float* in = a.in;
-  const float* zero = reinterpret_cast<const float*>(a.zero);
+  const char* in = reinterpret_cast<const char*>(a.in);
+  const char* wgt = reinterpret_cast<const char*>(a.w);
+  const char* zero = reinterpret_cast<const char*>(a.zero);
 
   for (int e = threadIdx.x; e < (kCbRows + 1) * ACC_LD; e += kCbThreads) sAcc[e] = 0.0f;
 
@@ -670,9 +680,9 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
   };
   auto load_a = [&](int idx_p1, f32x4(&dst)[QH]) {
     const int idx = __shfl(idx_p1, r, 64) - 1;
-    const float* src = idx >= 0 ? in + (long long)idx * CIN + h * (CIN / 2) : zero;
+    const char* src = idx >= 0 ? in + ((long long)idx * CIN + h * (CIN / 2)) * EB : zero;
 #pragma unroll
-    for (int q = 0; q < QH; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    for (int q = 0; q < QH; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + 16 * q);
   };
   f32x4 rw[W_LD];
   auto load_w = [&](int ks) {
@@ -680,10 +690,10 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 #pragma unroll
     for (int t = 0; t < W_LD; ++t) {
       const int e = t * kCbThreads + (int)threadIdx.x;
-      const int oc = e / (CIN / 4), q = e % (CIN / 4);
+      const int oc = e / QR, q = e % QR;
       const int goc = col0 + oc;
       const bool ok = e < W_Q && goc < a.cout;
-      const float* src = ok ? a.w + ((long long)goc * a.kvol + kk) * CIN + 4 * q : zero;
+      const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * EB + 16 * q : zero;
       rw[t] = *reinterpret_cast<const f32x4*>(src);
     }
   };
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 #pragma unroll
     for (int t = 0; t < W_LD; ++t) {
       const int e = t * kCbThreads + (int)threadIdx.x;
-      const int oc = e / (CIN / 4), q = e % (CIN / 4);
+      const int oc = e / QR, q = e % QR;
       if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
     }
   };
@@ -705,16 +715,21 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[t][i] = 0.0f;
-    const char* pb = sWb + buf * COUT_PAD * W_ROW + r * W_ROW + h * (CIN * 2);
+    const char* pb = sWb + buf * COUT_PAD * W_ROW + r * W_ROW + h * (CIN * EB / 2);
 #pragma unroll
     for (int j = 0; j < QH; ++j) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + t * 32 * W_ROW + 16 * j);
-        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, ra[j].x, d[t], 0, 0, 0);
-        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, ra[j].y, d[t], 0, 0, 0);
-        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, ra[j].z, d[t], 0, 0, 0);
-        d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, ra[j].w, d[t], 0, 0, 0);
+        if constexpr (EB == 4) {
+          d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, ra[j].x, d[t], 0, 0, 0);
+          d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, ra[j].y, d[t], 0, 0, 0);
+          d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, ra[j].z, d[t], 0, 0, 0);
+          d[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, ra[j].w, d[t], 0, 0, 0);
+        } else {
+          d[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, ra[j]),
+                                                         d[t], 0, 0, 0);
+        }
       }
     }
     const int rp = __shfl(row_p1, r, 64);
@@ -780,19 +795,19 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
       if (col >= a.cout) continue;
       float v = vv[j] + (a.bias ? a.bias[col] : 0.0f);
       if (a.scale || a.shift) v = v * (a.scale ? a.scale[col] : 1.0f) + (a.shift ? a.shift[col] : 0.0f);
-      if (a.residual) v += a.residual[row * a.cout + col];
+      if (a.residual) v += Elem<T>::load(reinterpret_cast<const T*>(a.residual) + row * a.cout + col);
       if (a.relu) v = fmaxf(v, 0.0f);
-      a.out[row * a.cout + col] = v;
+      Elem<T>::store(reinterpret_cast<T*>(a.out) + row * a.cout + col, v);
     }
   }
 }
 
-template <int CIN, int COUT_PAD, int WAVES>
+template <typename T, int CIN, int COUT_PAD, int WAVES>
 int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
   constexpr int R = 32 * WAVES;
-  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * 4 + 16);
+  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * sizeof(T) + 16);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = spconv_cb<CIN, COUT_PAD, WAVES>;
+  auto kern = spconv_cb<T, CIN, COUT_PAD, WAVES>;
   VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   kern<<<grid, 64 * WAVES, lds, stream>>>(a);
@@ -801,18 +816,40 @@ int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
 }
 
 // 1 = not eligible
-int32_t dispatch_cb(const ConvArgs& a, hipStream_t s) {
-  if (a.dtype != VX_F32 || a.perm || (reinterpret_cast<uintptr_t>(a.in) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15) ||
-      a.w_si != 1 || a.w_sk != a.cin || a.w_so != (long long)a.kvol * a.cin)
-    return 1;
+template <typename T>
+int32_t dispatch_cb_t(const ConvArgs& a, hipStream_t s) {
   const bool wide = a.cout > 32;       // Cout > 64 is tiled over blockIdx.y in slices of 64
-  if (a.cout > 128) return 1;
   switch (a.cin) {
-    case 16: return wide ? launch_cb<16, 64, VX_CB_WAVES>(a, s) : launch_cb<16, 32, VX_CB_WAVES>(a, s);
-    case 32: return wide ? launch_cb<32, 64, VX_CB_WAVES>(a, s) : launch_cb<32, 32, VX_CB_WAVES>(a, s);
-    case 64: return wide ? launch_cb<64, 64, VX_CB_WAVES_64>(a, s) : launch_cb<64, 32, VX_CB_WAVES>(a, s);
+    case 16:
+      if constexpr (sizeof(T) == 4)
+        return wide ? launch_cb<T, 16, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 16, 32, VX_CB_WAVES>(a, s);
+      else
+        return 1;                      // bf16 rows of 16 channels: half a row is less than one 16-byte quad
+    case 32: return wide ? launch_cb<T, 32, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 32, 32, VX_CB_WAVES>(a, s);
+    case 64:
+      if constexpr (sizeof(T) == 4)
+        return wide ? launch_cb<T, 64, 64, VX_CB_WAVES_64>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
+      else
+        return wide ? launch_cb<T, 64, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
+    case 128:
+      if constexpr (sizeof(T) == 2 && VX_CB_BF16_128)
+        return wide ? launch_cb<T, 128, 64, VX_CB_WAVES_64>(a, s) : launch_cb<T, 128, 32, VX_CB_WAVES>(a, s);
+      else
+        return 1;
     default: return 1;
   }
+}
+
+int32_t dispatch_cb(const ConvArgs& a, hipStream_t s) {
+  if (a.perm || (reinterpret_cast<uintptr_t>(a.in) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15) ||
+      a.w_si != 1 || a.w_sk != a.cin || a.w_so != (long long)a.kvol * a.cin || a.cout > 128)
+    return 1;
+  if (a.dtype == VX_F32) return dispatch_cb_t<float>(a, s);
+  // bf16, measured on the FHD layers (tools/conv_probe.py 8 bf16): compaction wins at 32->64 (-12 %) and 64->64 (-16 %),
+  // ties at 64->128, loses at 32->32 (+3 %) and 128->128 (+38 %: both Cout slices re-gather every row)
+  if (a.dtype == VX_BF16 && VX_CB_BF16 && (a.cin == 32 || a.cin == 64) && a.cout > 32 && a.cout <= 64)
+    return dispatch_cb_t<__bf16>(a, s);
+  return 1;
 }
 
 template <typename T, int CIN, int COUT_PAD>
