@@ -616,15 +616,20 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
 #ifndef VX_CB_BF16
 #define VX_CB_BF16 1
 #endif
+#ifndef VX_CB_NS_64
+#define VX_CB_NS_64 2      // ... with two waves per pair group (32 of the 64 channels each): 16 waves on a 256-row tile
+#endif
 #ifndef VX_CB_WAVES_64
-#define VX_CB_WAVES_64 8   // Cin = 64, Cout >= 64: W_k is 16 KB per offset, a 256-row tile halves its re-reads
+#define VX_CB_WAVES_64 16  // Cin = 64, Cout >= 64: W_k is 16 KB per offset, a 256-row tile halves its re-reads
 #endif
 
-template <typename T, int CIN, int COUT_PAD, int WAVES>
+// NS waves share one 32-pair group, each taking Cout/NS of its output channels (more, lighter waves per tile).
+template <typename T, int CIN, int COUT_PAD, int WAVES, int NS>
 __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(ConvArgs a) {
-  constexpr int kCbRows = 32 * WAVES, kCbThreads = 64 * WAVES;
+  constexpr int kCbRows = 32 * WAVES / NS, kCbThreads = 64 * WAVES;
+  static_assert(kCbRows % 64 == 0 && (COUT_PAD / 32) % NS == 0, "tile shape");
   constexpr int NE = kCbRows / 64;                   // neighbour entries per lane
-  constexpr int NT = COUT_PAD / 32;
+  constexpr int NT = COUT_PAD / 32 / NS;             // 32-channel tiles per wave
   constexpr int EB = (int)sizeof(T);
   constexpr int QR = CIN * EB / 16;                  // 16-byte quads per row
   constexpr int QH = QR / 2;                         // quads per lane half (half a row)
@@ -639,6 +644,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
+  const int grp = wave / NS, t0 = (wave % NS) * NT;  // this wave's pair group and first channel tile
   const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
   const int col0 = blockIdx.y * COUT_PAD;
   const char* in = reinterpret_cast<const char*>(a.in);
@@ -659,10 +665,10 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
         if (row0 + lane + 64 * j < a.n_out) e[j] = t[lane + 64 * j];
     }
   };
-  // compaction of the tile's entries; this wave keeps pairs [32*wave, 32*wave + 32):
+  // compaction of the tile's entries; this wave keeps pairs [32*grp, 32*grp + 32):
   // lanes 0..31 receive (input row + 1, local output row + 1) of their slot, 0 = empty slot
   auto my_group = [&](const int (&e)[NE], int& idx_p1, int& row_p1) {
-    int base = -32 * wave, ii = 0, qq = 0;
+    int base = -32 * grp, ii = 0, qq = 0;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       const unsigned long long m = __ballot(e[j] >= 0);
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
     }
     idx_p1 = lane < 32 ? ii : 0;
     row_p1 = lane < 32 ? qq : 0;
-    return base + 32 * wave;       // pairs of this offset in the tile
+    return base + 32 * grp;        // pairs of this offset in the tile
   };
   auto load_a = [&](int idx_p1, f32x4(&dst)[QH]) {
     const int idx = __shfl(idx_p1, r, 64) - 1;
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[t][i] = 0.0f;
-    const char* pb = sWb + buf * COUT_PAD * W_ROW + r * W_ROW + h * (CIN * EB / 2);
+    const char* pb = sWb + buf * COUT_PAD * W_ROW + (t0 * 32 + r) * W_ROW + h * (CIN * EB / 2);
 #pragma unroll
     for (int j = 0; j < QH; ++j) {
 #pragma unroll
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
       }
     }
     const int rp = __shfl(row_p1, r, 64);
-    float* arow = sAcc + (rp > 0 ? rp - 1 : kCbRows) * ACC_LD + 4 * h;   // empty slots add zeros to the dump row
+    float* arow = sAcc + (rp > 0 ? rp - 1 : kCbRows) * ACC_LD + t0 * 32 + 4 * h;   // empty slots add zeros to the dump row
     // no other wave touches this row during this offset: plain read-add-write (ds_add_f32 measured 4-5x
     // slower for the whole kernel: LDS float atomics do not run at the ds_read / ds_write rate)
 #pragma unroll
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
     cnt_nxt = my_group(en, idx_nxt, row_nxt);
     load_w(k + 1);
     load_a(idx_nxt, nxt);
-    if (32 * wave < cnt_cur) mfma_group(buf, cur, row_cur);
+    if (32 * grp < cnt_cur) mfma_group(buf, cur, row_cur);
     store_w(buf ^ 1);
     __syncthreads();
   };
@@ -802,12 +808,12 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
   }
 }
 
-template <typename T, int CIN, int COUT_PAD, int WAVES>
+template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1>
 int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
-  constexpr int R = 32 * WAVES;
+  constexpr int R = 32 * WAVES / NS;
   constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * sizeof(T) + 16);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = spconv_cb<T, CIN, COUT_PAD, WAVES>;
+  auto kern = spconv_cb<T, CIN, COUT_PAD, WAVES, NS>;
   VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   kern<<<grid, 64 * WAVES, lds, stream>>>(a);
@@ -828,12 +834,12 @@ int32_t dispatch_cb_t(const ConvArgs& a, hipStream_t s) {
     case 32: return wide ? launch_cb<T, 32, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 32, 32, VX_CB_WAVES>(a, s);
     case 64:
       if constexpr (sizeof(T) == 4)
-        return wide ? launch_cb<T, 64, 64, VX_CB_WAVES_64>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
+        return wide ? launch_cb<T, 64, 64, VX_CB_WAVES_64, VX_CB_NS_64>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
       else
         return wide ? launch_cb<T, 64, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
     case 128:
       if constexpr (sizeof(T) == 2 && VX_CB_BF16_128)
-        return wide ? launch_cb<T, 128, 64, VX_CB_WAVES_64>(a, s) : launch_cb<T, 128, 32, VX_CB_WAVES>(a, s);
+        return wide ? launch_cb<T, 128, 64, 8>(a, s) : launch_cb<T, 128, 32, VX_CB_WAVES>(a, s);
       else
         return 1;
     default: return 1;
