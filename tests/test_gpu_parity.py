@@ -556,3 +556,29 @@ def test_frame_pipeline_bitwise_equals_single_batch(dev):
     b = pipe(frames[:3], grid, join=False)
     torch.cuda.synchronize()
     assert torch.equal(a, ref) and torch.equal(b, ref[:3])
+
+
+@pytest.mark.parametrize("n_sites,ksize,cin,cout", [(7, 3, 16, 16), (33, 1, 32, 32), (129, 3, 64, 64), (300, 5, 16, 32),
+                                                     (257, 3, 64, 128), (1, 3, 32, 64)])
+def test_compaction_kernel_edge_shapes(n_sites, ksize, cin, cout, dev):
+    """Per-offset compaction kernel on tiny / ragged tiles, 1x1x1 and 5x5x5 kernels (125 offsets), Cout tiled
+    over blockIdx.y, forward and dgrad, against the oracle and bitwise against itself on a second run."""
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(n_sites * 31 + ksize)
+    shape = [6, 12, 12]
+    coords = random_sites(rng, 1, shape, n_sites)
+    feat = rng.normal(size=(coords.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, ksize, ksize, ksize, cin)) / np.sqrt(ksize ** 3 * cin)).astype(np.float32)
+    nbr = so.rulebook_subm(coords, shape, ksize)
+    ref = so.conv_fwd(feat, w, nbr, None)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 1, shape, ksize)
+    x, wt = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev)
+    got = ops.conv_fwd(x, wt, rb, compact=True)
+    again = ops.conv_fwd(x, wt, rb, compact=True)
+    assert torch.equal(got, again)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6)
+    dout = rng.normal(size=(coords.shape[0], cout)).astype(np.float32)
+    din_ref = so.conv_dgrad(dout, w, nbr, coords.shape[0])
+    din = ops.conv_dgrad(torch.from_numpy(dout).to(dev), wt, rb).cpu().numpy()
+    assert np.abs(din - din_ref).max() <= 1e-4 * max(np.abs(din_ref).max(), 1e-6)
