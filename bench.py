@@ -238,11 +238,11 @@ def main():
     if a.full_net:
         if a.geometry != "VISTA" or a.backbone != "MultiViewBackbone" or a.streams != 1:
             raise SystemExit("--full-net needs --geometry VISTA --backbone MultiViewBackbone (ohs.py:44-47 fixes the map sizes)")
-        from vista_amd.dense_tail import OHS_Multiview
+        from vista_amd.dense_tail import OHS_Multiview, fuse_for_inference
         torch.manual_seed(1234)     # dense-tail weights: torch default init, BN in eval mode with default statistics
         det = OHS_Multiview().eval()
         det.backbone = None         # the sparse part runs through the fused engine above
-        tail = det.to(dev).to(dtype).dense_tail
+        tail = fuse_for_inference(det).to(dev).to(dtype).dense_tail
 
     dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier, a.streams, tail)
     if dist is not None:

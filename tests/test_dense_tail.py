@@ -100,3 +100,31 @@ def test_detector_registry_names():
     assert det.ca_neck.bev_block_res == (40, 40) and det.ca_neck.rv_block_res == (40, 12)
     with pytest.raises(NotImplementedError):
         det({}, return_loss=True)
+
+
+def test_fuse_for_inference_keeps_outputs():
+    torch.manual_seed(3)
+    neck = dt.RPNT(layer_nums=[1, 1], ds_layer_strides=[1, 2], ds_num_filters=[8, 16], us_layer_strides=[1, 2],
+                   us_num_filters=[12, 6], num_input_features=10).eval()
+    head = dt.DeepMultiGroupOHSHeadClear_Decouple(mode="bev", in_channels=18, tasks=dt.VISTA_TASKS[:2]).eval()
+    with torch.no_grad():
+        for m in list(neck.modules()) + list(head.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+        x = torch.randn(2, 10, 16, 12)
+        y0 = neck(x)
+        p0 = head((y0, y0))
+        dt.fuse_for_inference(neck)
+        dt.fuse_for_inference(head)
+        assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in list(neck.modules()) + list(head.modules()))
+        y1 = neck(x)
+        p1 = head((y1, y1))
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=1e-4, atol=1e-5)
+    for a, b in zip(p0, p1):
+        np.testing.assert_allclose(b["box_preds"].numpy(), a["box_preds"].numpy(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        dt.fuse_for_inference(dt.RPNT(layer_nums=[1], ds_layer_strides=[1], ds_num_filters=[4], us_layer_strides=[1],
+                                      us_num_filters=[4], num_input_features=4))       # still in training mode

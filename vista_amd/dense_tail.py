@@ -336,6 +336,23 @@ class DeepMultiGroupOHSHeadClear_Decouple(nn.Module):
         return [task((x_sem, x_geo), return_loss) for task in self.tasks]
 
 
+def fuse_for_inference(module):
+    """Fold every eval-mode BatchNorm2d that directly follows a Conv2d / ConvTranspose2d inside an nn.Sequential into
+    that conv's weight and bias (the same folding engine.FusedBackbone does for the sparse convs); the BN slot becomes
+    nn.Identity, so state_dict keys of the convs are unchanged. In place; returns the module."""
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+    for seq in [m for m in module.modules() if isinstance(m, nn.Sequential)]:
+        names = list(seq._modules)
+        for a, b in zip(names, names[1:]):
+            conv, bn = seq._modules[a], seq._modules[b]
+            if isinstance(conv, (nn.Conv2d, nn.ConvTranspose2d)) and isinstance(bn, nn.BatchNorm2d):
+                if conv.training or bn.training:
+                    raise RuntimeError("fuse_for_inference needs eval mode")
+                seq._modules[a] = fuse_conv_bn_eval(conv, bn, transpose=isinstance(conv, nn.ConvTranspose2d))
+                seq._modules[b] = nn.Identity()
+    return module
+
+
 # --------------------------------------------------------------------------------------------- detector
 VISTA_TASKS = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "construction_vehicle"]),
                dict(num_class=2, class_names=["bus", "trailer"]), dict(num_class=1, class_names=["barrier"]),
