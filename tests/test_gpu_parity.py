@@ -582,3 +582,26 @@ def test_compaction_kernel_edge_shapes(n_sites, ksize, cin, cout, dev):
     din_ref = so.conv_dgrad(dout, w, nbr, coords.shape[0])
     din = ops.conv_dgrad(torch.from_numpy(dout).to(dev), wt, rb).cpu().numpy()
     assert np.abs(din - din_ref).max() <= 1e-4 * max(np.abs(din_ref).max(), 1e-6)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64), (64, 128), (128, 128)])
+def test_conv_on_fully_dense_grid(cin, cout, dev):
+    """Every site active: tiles whose pair count per offset reaches the tile size (all waves busy, no padding
+    slots) and, at the grid faces, drops to partial groups. Forward of both kernel families vs the oracle."""
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    shape = [4, 16, 16]
+    zz, yy, xx = np.meshgrid(np.arange(4), np.arange(16), np.arange(16), indexing="ij")
+    one = np.stack([np.zeros(zz.size, dtype=np.int64), zz.ravel(), yy.ravel(), xx.ravel()], 1)
+    coords = np.concatenate([one, one + [1, 0, 0, 0]]).astype(np.int32)          # 2 frames x 1024 sites, sorted
+    feat = rng.normal(size=(coords.shape[0], cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    nbr = so.rulebook_subm(coords, shape, 3)
+    ref = so.conv_fwd(feat, w, nbr, None)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    np.testing.assert_array_equal(rb.nbr.cpu().numpy(), nbr)
+    x, wt = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev)
+    for compact in (True, False):
+        got = ops.conv_fwd(x, wt, rb, compact=compact).cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), compact
