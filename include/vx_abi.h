@@ -192,6 +192,20 @@ int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int3
                     int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Rotated BEV boxes [x1, y1, x2, y2, ry] (post-processing, outside the sparse hot path).
+ * vx_boxes_overlap_bev: d_out f32[num_a][num_b] = overlap area (iou = 0) or IoU (iou = 1). Replaces
+ *   boxes_overlap_bev_gpu / boxes_iou_bev_gpu (det3d/ops/iou3d_nms/src/iou3d_nms.cpp:37-77).
+ * vx_nms_bev: greedy NMS over boxes ALREADY sorted by descending score; rotated = 1 uses the rotated IoU
+ *   (nms_gpu, iou3d_nms.cpp:79-126), 0 the axis-aligned IoU of the first four fields (nms_normal_gpu, :129-176).
+ *   d_keep int64[num_boxes] receives the kept indices in order, *h_num_keep their count (one host sync).
+ * ------------------------------------------------------------------------------------------- */
+int32_t vx_boxes_overlap_bev(const float* d_boxes_a, int32_t num_a, const float* d_boxes_b, int32_t num_b,
+                             float* d_out, int32_t iou, void* stream);
+size_t vx_nms_workspace_bytes(int32_t num_boxes);
+int32_t vx_nms_bev(const float* d_boxes, int32_t num_boxes, float thresh, int32_t rotated, int64_t* d_keep,
+                   int64_t* h_num_keep, void* d_workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
