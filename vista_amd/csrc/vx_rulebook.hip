@@ -39,6 +39,9 @@ __global__ __launch_bounds__(kThreads) void hash_build(const int* __restrict__ c
 }
 
 // submanifold: one thread per (k, o), o fastest -> coalesced coordinate reads and table writes
+// Submanifold offsets come in mirrored pairs: nbr[k][o] = j  <=>  nbr[K-1-k][j] = o. Only the first half of the
+// offsets is looked up (blockIdx.y = 0 .. K/2); a hit also fills the mirrored entry (each entry has exactly one
+// writer), the centre offset is the identity, and the caller pre-fills rows K/2+1 .. K-1 with -1.
 __global__ __launch_bounds__(kThreads) void subm_nbr(const int* __restrict__ coords, long long n,
                                                      ConvGeom g, const VxSlot* __restrict__ t,
                                                      long long mask, int* __restrict__ nbr,
@@ -46,6 +49,10 @@ __global__ __launch_bounds__(kThreads) void subm_nbr(const int* __restrict__ coo
   const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
   const int k = blockIdx.y;
   if (o >= n) return;
+  if (2 * k + 1 == g.kvol) {
+    nbr[(long long)k * ld + o] = (int)o;
+    return;
+  }
   const int kx = k % g.k[2], ky = (k / g.k[2]) % g.k[1], kz = k / (g.k[2] * g.k[1]);
   const int4 c = *reinterpret_cast<const int4*>(coords + 4 * o);
   const int z = c.y + kz - g.k[0] / 2, y = c.z + ky - g.k[1] / 2, x = c.w + kx - g.k[2] / 2;
@@ -53,6 +60,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr(const int* __restrict__ coo
   if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2])
     r = vx_hash_find(t, mask, lin_idx(c.x, z, y, x, g.in_shape));
   nbr[(long long)k * ld + o] = r;
+  if (r >= 0) nbr[(long long)(g.kvol - 1 - k) * ld + r] = (int)o;
 }
 
 // strided conv phase 1: every input marks the outputs it feeds in the occupancy bitmap
@@ -175,8 +183,12 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_ranked(const int* __restric
                                                             const uint2* __restrict__ rank,
                                                             int* __restrict__ nbr, long long ld) {
   const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
-  const int k = blockIdx.y;
+  const int k = blockIdx.y;                          // first half of the offsets + centre (see subm_nbr)
   if (o >= n) return;
+  if (2 * k + 1 == g.kvol) {
+    nbr[(long long)k * ld + o] = (int)o;
+    return;
+  }
   const int kx = k % g.k[2], ky = (k / g.k[2]) % g.k[1], kz = k / (g.k[2] * g.k[1]);
   const int4 c = *reinterpret_cast<const int4*>(coords + 4 * o);
   const int z = c.y + kz - g.k[0] / 2, y = c.z + ky - g.k[1] / 2, x = c.w + kx - g.k[2] / 2;
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_ranked(const int* __restric
   if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2])
     r = rank_lookup(rank, lin_idx(c.x, z, y, x, g.in_shape));
   nbr[(long long)k * ld + o] = r;
+  if (r >= 0) nbr[(long long)(g.kvol - 1 - k) * ld + r] = (int)o;
 }
 
 // ---- pair-list view: wavefront-ballot compaction ------------------------------------------------
@@ -381,7 +394,10 @@ extern "C" int32_t vx_rulebook_subm(const int32_t* d_coords, int64_t n, int32_t 
   }
   int32_t rc = build_table(d_coords, n, g, w, stream);
   if (rc) return rc;
-  dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)g.kvol);
+  const int half = g.kvol / 2;                       // odd kvol: offsets 0..half-1 mirror half+1..kvol-1
+  if (half > 0)
+    VX_HIP(hipMemsetAsync(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream));
+  dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)(half + 1));
   subm_nbr<<<grid, kThreads, 0, stream>>>(d_coords, n, g, w.table, w.cap - 1, d_nbr, nbr_ld);
   VX_LAUNCH_CHECK();
   return VX_OK;
@@ -474,7 +490,10 @@ extern "C" int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, i
              "rulebook_subm_ranked: bad geometry (odd kernel sizes <= 125 offsets required)");
   if (n == 0) return VX_OK;
   VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm_ranked: bad table pointer / stride");
-  dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)g.kvol);
+  const int half = g.kvol / 2;
+  if (half > 0)
+    VX_HIP(hipMemsetAsync(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream));
+  dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)(half + 1));
   subm_nbr_ranked<<<grid, kThreads, 0, stream>>>(d_coords, n, g, (const uint2*)d_rank, d_nbr, nbr_ld);
   VX_LAUNCH_CHECK();
   return VX_OK;
