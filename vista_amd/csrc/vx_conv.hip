@@ -185,6 +185,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kW8Threads = 512;
 constexpr int kW8Rows = 256;
+constexpr int kNumCUs = 256;             // MI355X: 8 XCDs x 32 CUs
 constexpr int kRowBytes = 256;          // staged bytes per row per chunk
 
 template <typename T>
@@ -244,8 +245,9 @@ extern "C" int32_t vx_debug_read(unsigned long long* h8) {
 #define VX_STAMP_FLUSH
 #endif
 
+// Body of the LDS-staged row-stationary kernel for row tile `tile` and output columns [col0, col0 + COUT_PAD).
 template <typename T, int CIN, int COUT_PAD>
-__global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
+__device__ __forceinline__ void w8_body(const ConvArgs& a, const long long tile, const int col0) {
   constexpr int VPQ = Elem<T>::VPQ;
   constexpr int CK = kRowBytes / (int)sizeof(T);      // staged values per chunk (64 / 128)
   constexpr int QPR = kRowBytes / 16;                 // 16-byte pieces per staged row (16)
@@ -266,9 +268,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
   const T* zero = reinterpret_cast<const T*>(a.zero);
 
   const int r = lane & 31, h = lane >> 5;
-  const long long tile = xcd_remap(blockIdx.x, gridDim.x);
   const long long row0 = tile * kW8Rows + wave * 32;
-  const int col0 = blockIdx.y * COUT_PAD;
   const int nchunks = (a.kvol * CIN + CK - 1) / CK;
 
   unsigned wmask = 0;
@@ -430,6 +430,27 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
       if (a.relu) v = fmaxf(v, 0.0f);
       Elem<T>::store(out + orow * a.cout + col, v);
     }
+  }
+}
+
+template <typename T, int CIN, int COUT_PAD>
+__global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
+  w8_body<T, CIN, COUT_PAD>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y * COUT_PAD);
+}
+
+// Split-tail launch. The kernel keeps one workgroup per CU (its LDS holds two W chunks), so a grid of
+// G = 256*q + rem row tiles costs q + 1 rounds however small rem is: a single FHD frame has 309 tiles at
+// C = 128 and pays two rounds for 1.2 rounds of work. Here the first n_full = 256*q tiles run as usual and
+// each of the last `rem` tiles is taken by two workgroups computing half of the output columns each
+// (2*rem <= 256 workgroups -> one round of roughly half the duration). Only used for cout == COUT_PAD.
+template <typename T, int CIN, int COUT_PAD>
+__global__ __launch_bounds__(kW8Threads, 2) void spconv_w8_split_tail(ConvArgs a, int n_full) {
+  const int b = blockIdx.x;
+  if (b < n_full) {
+    w8_body<T, CIN, COUT_PAD>(a, xcd_remap(b, n_full), 0);
+  } else {
+    const int j = b - n_full;
+    w8_body<T, CIN, COUT_PAD / 2>(a, n_full + (j >> 1), (j & 1) * (COUT_PAD / 2));
   }
 }
 
@@ -608,6 +629,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
 // hence one wave; offsets are separated by the barrier: plain in-order sums, bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
 #ifndef VX_CB_WAVES
+#define VX_W8_SPLIT_TAIL 1  // split the last partial round of spconv_w8 over output-column halves
 #define VX_CB_WAVES 4      // waves (= 32-row groups) per workgroup of the compaction kernel
 #endif
 #ifndef VX_CB_BF16_128
@@ -872,6 +894,17 @@ int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
   dim3 grid((unsigned)vx_cdiv(a.n_out, kW8Rows), (unsigned)vx_cdiv(a.cout, COUT_PAD));
+  if constexpr (kLdsGather && COUT_PAD >= 64) {
+    const long long tiles = grid.x;
+    const long long rem = tiles % kNumCUs;
+    if (VX_W8_SPLIT_TAIL && a.cout == COUT_PAD && rem > 0 && 2 * rem <= kNumCUs) {
+      auto kt = spconv_w8_split_tail<T, CIN, COUT_PAD>;
+      VX_HIP(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      kt<<<dim3((unsigned)(tiles + rem)), kW8Threads, lds, stream>>>(a, (int)(tiles - rem));
+      VX_LAUNCH_CHECK();
+      return VX_OK;
+    }
+  }
   kern<<<grid, kW8Threads, lds, stream>>>(a);
   VX_LAUNCH_CHECK();
   return VX_OK;
