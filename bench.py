@@ -130,14 +130,14 @@ def dominant_kernel_roofline(timing, dtype):
         # fp32: intensity Cout/2 = 64 flop per gathered byte -> MFMA-bound (157.3 TFLOP/s fp32 matrix peak)
         return {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("f32"),
-                "kernel": "spconv_w8<float,128,128> (SubMConv3d 128->128, k=3)", **common}
+                "kernel": "spconv_w8_split_tail<float,128,128> (SubMConv3d 128->128, k=3; spconv_w8 body)", **common}
     # bf16: MFMA is 16x faster, the gather phase bounds the layer (bytes = pairs*Cin*s + N_out*Cout*s
     # + K*Cin*Cout*s + pairs*8, s = 2)
     nbytes = np.array([p_ * 128 * 2 + t["rb"].n_out * 128 * 2 + 27 * 128 * 128 * 2 + p_ * 8
                        for t, p_ in zip(sel, [pairs[id(t["rb"])] for t in sel])], dtype=np.float64)
     gbs = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
     return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-            "traffic": pmc_traffic("bf16"), "kernel": "spconv_w8<bf16,128,128> (SubMConv3d 128->128, k=3)",
+            "traffic": pmc_traffic("bf16"), "kernel": "spconv_w8_split_tail<bf16,128,128> (SubMConv3d 128->128, k=3; spconv_w8 body)",
             "bytes_per_launch": float(nbytes.mean()), **common}
 
 

@@ -78,14 +78,14 @@ def med(per, key, ctr):
     return st.median([c[ctr] for c in sel if c["_grid"] == g])
 
 
-specs = {"f32": ((q + "A", q + "B"), {"dominant_kernel": ("spconv_w8<float, 128, 128", 12692838, 681878, 128),
+specs = {"f32": ((q + "A", q + "B"), {"dominant_kernel": ("spconv_w8_split_tail<float, 128, 128", 12692838, 681878, 128),
                                       "c64_kernel": ("spconv_cb<float, 64, 64", 24411879, 1687797, 64),
                                       "c32_kernel": ("spconv_cb<float, 32, 32", 23826569, 2147993, 32)}),
-         "bf16": ((q + "C", q + "D"), {"dominant_kernel": ("spconv_w8IDF16bLi128ELi128E", 12692838, 681878, 128),
+         "bf16": ((q + "C", q + "D"), {"dominant_kernel": ("spconv_w8_split_tailIDF16bLi128ELi128E", 12692838, 681878, 128),
                                        "c64_kernel": ("spconv_cbIDF16bLi64ELi64E", 24411879, 1687797, 64)})}
 res = {"note": "rocprofv3 --pmc passes (separate runs: FETCH_SIZE+SQ+GRBM, then WRITE_SIZE+TCC) over tools/conv_probe.py 8 "
                "[f32|bf16] on the rulebooks of 8 FHD frames; medians over the launches of each kernel. dominant_kernel = SubMConv3d "
-               "128->128 k=3 (row-stationary spconv_w8, stage 3: 681,878 rows, 12,692,838 pairs); c64_kernel / c32_kernel = "
+               "128->128 k=3 (row-stationary spconv_w8 body launched through spconv_w8_split_tail: 2,664 row tiles = 10 full rounds of 256 + 104 tail tiles split over output-column halves; stage 3: 681,878 rows, 12,692,838 pairs); c64_kernel / c32_kernel = "
                "SubMConv3d 64->64 / 32->32 on the per-offset compaction kernel spconv_cb (stage 2: 1,687,797 rows, 24,411,879 "
                "pairs; stage 1: 2,147,993 rows, 23,826,569 pairs). FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is "
                "doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16 B/lane loads); GRBM_GUI_ACTIVE is "

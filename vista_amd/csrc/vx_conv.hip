@@ -628,8 +628,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
 // the LDS accumulator rows of those pairs. Within one offset an output row belongs to exactly one pair,
 // hence one wave; offsets are separated by the barrier: plain in-order sums, bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
-#ifndef VX_CB_WAVES
+#ifndef VX_W8_SPLIT_TAIL
 #define VX_W8_SPLIT_TAIL 1  // split the last partial round of spconv_w8 over output-column halves
+#endif
+#ifndef VX_CB_WAVES
 #define VX_CB_WAVES 4      // waves (= 32-row groups) per workgroup of the compaction kernel
 #endif
 #ifndef VX_CB_BF16_128
