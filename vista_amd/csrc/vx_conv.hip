@@ -185,7 +185,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kW8Threads = 512;
 constexpr int kW8Rows = 256;
-constexpr int kNumCUs = 256;             // MI355X: 8 XCDs x 32 CUs
 constexpr int kRowBytes = 256;          // staged bytes per row per chunk
 
 template <typename T>
@@ -882,6 +881,19 @@ int32_t dispatch_cb(const ConvArgs& a, hipStream_t s) {
   return 1;
 }
 
+// compute units of the current device (MI355X: 8 XCDs x 32 = 256; fewer in a partitioned mode), cached per device
+int cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 template <typename T, int CIN, int COUT_PAD>
 int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   // LDS-staged gather where a chunk carries enough MFMA work to hide its LDS round trip
@@ -898,8 +910,9 @@ int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)vx_cdiv(a.n_out, kW8Rows), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   if constexpr (kLdsGather && COUT_PAD >= 64) {
     const long long tiles = grid.x;
-    const long long rem = tiles % kNumCUs;
-    if (VX_W8_SPLIT_TAIL && a.cout == COUT_PAD && rem > 0 && 2 * rem <= kNumCUs) {
+    const int cus = cu_count();
+    const long long rem = tiles % cus;
+    if (VX_W8_SPLIT_TAIL && a.cout == COUT_PAD && rem > 0 && 2 * rem <= cus) {
       auto kt = spconv_w8_split_tail<T, CIN, COUT_PAD>;
       VX_HIP(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       kt<<<dim3((unsigned)(tiles + rem)), kW8Threads, lds, stream>>>(a, (int)(tiles - rem));
