@@ -515,6 +515,29 @@ def test_conv_fwd_streaming_w_kernel(cin, cout, dev):
     assert torch.equal(got, base)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,n_sites", [(128, 76000), (128, 9000), (64, 70000)])
+def test_conv_fwd_split_tail_bitwise(cin, n_sites, dtype, dev):
+    """spconv_w8's split-tail launch (last partial round of 256-row tiles taken by two workgroups per tile, half of
+    the output columns each) sums in the same order as the plain grid: bitwise equal. 76000 / 70000 rows = one full
+    round of 256 tiles + a tail; 9000 rows = tail only."""
+    from vista_amd import ops
+    rng = np.random.default_rng(n_sites + cin)
+    shape = [5, 200, 200]
+    coords = random_sites(rng, 1, shape, n_sites)
+    n = coords.shape[0]
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).to(dev).to(td)
+    wt = torch.from_numpy((rng.normal(size=(128, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev).to(td)
+    b = torch.from_numpy(rng.normal(size=(128,)).astype(np.float32)).to(dev)
+    res = torch.from_numpy(rng.normal(size=(n, 128)).astype(np.float32)).to(dev).to(td)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 1, shape, 3)
+    got = ops.conv_fwd(x, wt, rb, bias=b, residual=res, relu=True, compact=False)
+    base = ops.conv_fwd(x, wt, rb, bias=b, residual=res, relu=True, compact=False, split_tail=False)
+    assert torch.equal(got, base)
+    assert float(got.float().abs().max()) > 0
+
+
 def test_voxelize_batch_equals_per_frame(dev):
     """One batched launch sequence == per-frame calls + collate (bit-exact, incl. the mean)."""
     from vista_amd import ops

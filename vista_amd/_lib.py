@@ -16,6 +16,7 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 VX_F32, VX_BF16 = 0, 1
 VX_EPI_RELU = 1
 VX_CONV_NO_COMPACT = 0x100
+VX_CONV_NO_SPLIT_TAIL = 0x200
 
 # name -> (restype, argtypes); mirrors include/vx_abi.h one to one
 SIGNATURES = {

@@ -38,6 +38,7 @@ struct ConvArgs {
   int dtype;            // VX_F32 | VX_BF16 (element type of in / w / residual / out)
   const int* perm;      // optional: tile row j computes output row perm[j] (table is pre-permuted)
   const void* zero;     // 512 zero bytes in device memory: what a missing neighbour reads
+  int no_split;         // launch spconv_w8's plain grid (VX_CONV_NO_SPLIT_TAIL)
 };
 
 // bijective XCD-aware remap: consecutive tiles (which share gathered neighbours) run on one XCD
@@ -912,7 +913,7 @@ int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
     const long long tiles = grid.x;
     const int cus = cu_count();
     const long long rem = tiles % cus;
-    if (VX_W8_SPLIT_TAIL && a.cout == COUT_PAD && rem > 0 && 2 * rem <= cus) {
+    if (VX_W8_SPLIT_TAIL && !a.no_split && a.cout == COUT_PAD && rem > 0 && 2 * rem <= cus) {
       auto kt = spconv_w8_split_tail<T, CIN, COUT_PAD>;
       VX_HIP(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       kt<<<dim3((unsigned)(tiles + rem)), kW8Threads, lds, stream>>>(a, (int)(tiles - rem));
@@ -1205,6 +1206,7 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
   a.shift = d_shift;
   a.residual = (const float*)d_residual;
   a.relu = (flags & VX_EPI_RELU) ? 1 : 0;
+  a.no_split = (flags & VX_CONV_NO_SPLIT_TAIL) ? 1 : 0;
   a.out = (float*)d_out;
   a.dtype = dtype;
   a.perm = d_perm;
@@ -1263,6 +1265,7 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.flip_k = subm ? 1 : 0;
   a.bias = a.scale = a.shift = a.residual = nullptr;
   a.relu = 0;
+  a.no_split = 0;
   a.out = (float*)d_din;
   a.dtype = dtype;
   a.perm = nullptr;

@@ -313,13 +313,14 @@ def pack_weight(weight):
 
 
 def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False,
-             sort_rows=False, wpack=None, compact=True):
+             sort_rows=False, wpack=None, compact=True, split_tail=True):
     """features [n_in,Cin], weight [Cout,kz,ky,kx,Cin] (KRSC) -> [n_out,Cout]; fused epilogue
     relu?((acc + bias) * scale + shift + residual). sort_rows: run on the rulebook's mask-sorted
     row order (same bits out); wpack: packed weight copy -> barrier-free streaming-W kernel (fp32).
     Both are OFF by default: measured on MI355X they only pay together, on the
     sparse strided layers, and the sort costs what they save. compact=False forces the row-stationary
-    kernels where the library would pick the per-offset compaction kernel (fp32, Cin <= 64)."""
+    kernels where the library would pick the per-offset compaction kernel (fp32, Cin <= 64); split_tail=False
+    launches the row-stationary kernel's plain grid (bitwise the same output, for A/B timing and tests)."""
     _need_gpu(features, "features")
     if features.dtype not in _DT:
         raise ValueError(f"unsupported feature dtype {features.dtype}")
@@ -349,7 +350,8 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
                                                    esize=features.element_size()):
         rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(nbr),
                                    max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
-                                   _ptr(residual), (L.VX_EPI_RELU if relu else 0) | (0 if compact else L.VX_CONV_NO_COMPACT),
+                                   _ptr(residual), (L.VX_EPI_RELU if relu else 0) | (0 if compact else L.VX_CONV_NO_COMPACT)
+                                   | (0 if split_tail else L.VX_CONV_NO_SPLIT_TAIL),
                                    _ptr(perm), _ptr(wpack),
                                    _ptr(out), _DT[features.dtype], _stream())
     L.check(rc, "vx_spconv_fwd")
