@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--full-net", action="store_true",
                     help="BASELINE configs[2]: MultiViewBackbone + dense tail (necks, cross-view attention, OHS head; "
                          "stock PyTorch-ROCm ops) on the VISTA geometry")
+    ap.add_argument("--postprocess", action="store_true",
+                    help="with --full-net: add box decode + score filter + rotated NMS (head.predict) to the step")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of a step on alternating HIP streams (vista_amd.engine.FramePipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -242,7 +244,13 @@ def main():
         torch.manual_seed(1234)     # dense-tail weights: torch default init, BN in eval mode with default statistics
         det = OHS_Multiview().eval()
         det.backbone = None         # the sparse part runs through the fused engine above
-        tail = fuse_for_inference(det).to(dev).to(dtype).dense_tail
+        det = fuse_for_inference(det).to(dev).to(dtype)
+        tail = det.dense_tail
+        if a.postprocess:
+            from vista_amd.postprocess import VISTA_TEST_CFG
+
+            def tail(bev, rv):
+                return det.bbox_head.predict({}, det.dense_tail(bev, rv), VISTA_TEST_CFG)
 
     dt, timing, out = timed_infer(gen, engine, frames, grid, a.steps, a.warmup, barrier, a.streams, tail)
     if dist is not None:
@@ -255,7 +263,8 @@ def main():
     res = {
         "metric": (f"backbone frames/sec (voxelize + mean VFE + {a.backbone} forward)" if not a.full_net else
                    "full-net frames/sec (voxelize + mean VFE + MultiViewBackbone + necks + cross-view attention + "
-                   "OHS head forward; no loss / box decode / NMS)"),
+                   "OHS head forward" + ("; no loss / box decode / NMS)" if not a.postprocess else
+                                         " + box decode + score filter + rotated NMS)")),
         "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16",

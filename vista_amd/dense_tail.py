@@ -335,6 +335,13 @@ class DeepMultiGroupOHSHeadClear_Decouple(nn.Module):
         x_sem, x_geo = self.sem_conv(xs[0]), self.geo_conv(xs[1])
         return [task((x_sem, x_geo), return_loss) for task in self.tasks]
 
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        """Decode + (double-flip merge) + score filter + rotated NMS -> one detection dict per frame
+        (clear_mg_ohs_head.py:569-730; vista_amd.postprocess)."""
+        from .postprocess import predict
+        return predict(preds_dicts, test_cfg, self.num_classes, self.box_coder,
+                       metadata=(example or {}).get("metadata") or None)
+
 
 def fuse_for_inference(module):
     """Fold every eval-mode BatchNorm2d that directly follows a Conv2d / ConvTranspose2d inside an nn.Sequential into
@@ -383,6 +390,7 @@ class OHS_Multiview(nn.Module):
                                            rv_size=(160, 12), rv_block_res=(40, 12), hidden_channels=512), NECKS)
         self.bbox_head = build_from_cfg(bbox_head or dict(type="DeepMultiGroupOHSHeadClear_Decouple", mode="bev",
                                                           in_channels=384, tasks=VISTA_TASKS), HEADS)
+        self.test_cfg = test_cfg
 
     def dense_tail(self, x_bev, x_rv, need_maps=False):
         """(BEV map, RV map) of the backbone -> list of per-task {"box_preds", "cls_preds"}."""
@@ -394,4 +402,7 @@ class OHS_Multiview(nn.Module):
             raise NotImplementedError("losses / target assignment are outside this path (SURVEY 8f)")
         feats = self.reader(example["voxels"], example["num_points"])
         x_bev, x_rv = self.backbone(feats, example["coordinates"], len(example["num_voxels"]), example["shape"][0])
-        return self.dense_tail(x_bev, x_rv)
+        preds = self.dense_tail(x_bev, x_rv)
+        if self.test_cfg is None:                      # raw head maps (per task box_preds / cls_preds)
+            return preds
+        return self.bbox_head.predict(example, preds, self.test_cfg)     # ohs.py:93
