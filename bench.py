@@ -52,6 +52,8 @@ def parse():
                     help="with --full-net: add box decode + score filter + rotated NMS (head.predict) to the step")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of a step on alternating HIP streams (vista_amd.engine.FramePipeline)")
+    ap.add_argument("--torch-bn", action="store_true",
+                    help="--mode train: stock torch BatchNorm1d/ReLU/add kernels instead of the fused libvx ones (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     return ap.parse_args()
@@ -126,8 +128,12 @@ def dominant_kernel_roofline(timing, dtype):
         flops.append(2.0 * pairs[id(rb)] * 128 * 128)
     flops = np.array(flops)
     tflops = float(flops.sum() / (ms.sum() * 1e-3) / 1e12)
+    # rocprofv3 --stats averages over EVERY launch of the kernel symbol: the k=27 SubM launches priced here plus the
+    # (3,1,1) last conv, which runs on the same <128,128> instantiation; `symbol_avg_launch_ms` is that average
+    sym = np.array([t["ev0"].elapsed_time(t["ev1"]) for t in timing
+                    if t["op"] == "conv" and t["cin"] == 128 and t["cout"] == 128])
     common = {"launches": int(len(sel)), "avg_launch_ms": float(ms.mean()), "flops_per_launch": float(flops.mean()),
-              "achieved_tflops": tflops}
+              "achieved_tflops": tflops, "symbol_launches": int(len(sym)), "symbol_avg_launch_ms": float(sym.mean())}
     if dtype == "fp32":
         # fp32: intensity Cout/2 = 64 flop per gathered byte -> MFMA-bound (157.3 TFLOP/s fp32 matrix peak)
         return {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

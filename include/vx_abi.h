@@ -196,6 +196,43 @@ int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int3
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm1d over sparse features [n][c] (fp32, c a power of two in [8, 512]), fused with the
+ * residual add and ReLU that follow it. Replaces the torch BatchNorm1d / add / ReLU passes over `.features`
+ * of det3d/models/backbones/scn.py:82-98 (block) and :333-364 (conv + BN + ReLU) in the training step
+ * (norm layer: det3d/models/utils/norm.py:62,99-103; SyncBatchNorm: det3d/torchie/apis/train.py:301 -- the
+ * caller all-reduces d_sums between the two halves of each pass, which is all SyncBN exchanges).
+ *
+ * forward : vx_bn_stats    d_sums f64[2c+1] = {sum x, sum x^2 per channel, n}   (ordered two-level reduction)
+ *           [all-reduce d_sums over ranks]
+ *           vx_bn_finalize d_mean, d_invstd f32[c] (biased variance + eps); running stats updated with
+ *                          `momentum` and the unbiased variance when the pointers are non-NULL
+ *           vx_bn_apply    y = relu?((x - mean) * invstd * gamma + beta + residual?); with relu, d_mask
+ *                          (n*c/8 bytes) receives one bit per element: y > 0
+ * backward: vx_bn_bwd_reduce d_sums f64[2c] = {sum g, sum g*xhat}, g = dy where the mask bit is set (all of
+ *                          dy when d_mask is NULL); d_param_grads f32[2c] (optional) = the same sums in fp32
+ *                          = {d beta, d gamma} of THIS rank
+ *           [all-reduce d_sums over ranks]
+ *           vx_bn_bwd_apply dx = gamma*invstd*(g - sum_g/N - xhat*sum_gxhat/N), N = *d_count (f64, the total
+ *                          row count, e.g. d_sums[2c] of the forward pass); d_dres (optional) receives g
+ * d_gamma / d_beta / d_residual / d_mask may be NULL. Workspace: vx_bn_workspace_bytes(c).
+ * ------------------------------------------------------------------------------------------- */
+size_t vx_bn_workspace_bytes(int32_t c);
+int32_t vx_bn_stats(const float* d_x, int64_t n, int32_t c, double* d_sums, void* d_workspace,
+                    size_t workspace_bytes, void* stream);
+int32_t vx_bn_finalize(const double* d_sums, int32_t c, float eps, float momentum, float* d_running_mean,
+                       float* d_running_var, float* d_mean, float* d_invstd, void* stream);
+int32_t vx_bn_apply(const float* d_x, int64_t n, int32_t c, const float* d_mean, const float* d_invstd,
+                    const float* d_gamma, const float* d_beta, const float* d_residual, int32_t relu,
+                    float* d_y, uint8_t* d_mask, void* stream);
+int32_t vx_bn_bwd_reduce(const float* d_dy, const float* d_x, const uint8_t* d_mask, int64_t n, int32_t c,
+                         const float* d_mean, const float* d_invstd, double* d_sums, float* d_param_grads,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+int32_t vx_bn_bwd_apply(const float* d_dy, const float* d_x, const uint8_t* d_mask, int64_t n, int32_t c,
+                        const float* d_mean, const float* d_invstd, const float* d_gamma,
+                        const double* d_sums, const double* d_count, float* d_dx, float* d_dres,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Rotated BEV boxes [x1, y1, x2, y2, ry] (post-processing, outside the sparse hot path).
  * vx_boxes_overlap_bev: d_out f32[num_a][num_b] = overlap area (iou = 0) or IoU (iou = 1). Replaces
  *   boxes_overlap_bev_gpu / boxes_iou_bev_gpu (det3d/ops/iou3d_nms/src/iou3d_nms.cpp:37-77).

@@ -57,6 +57,16 @@ SIGNATURES = {
                                   c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "vx_to_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
                               c_int32, c_void_p]),
+    "vx_bn_workspace_bytes": (c_size_t, [c_int32]),
+    "vx_bn_stats": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_bn_finalize": (c_int32, [c_void_p, c_int32, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "vx_bn_apply": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                              c_void_p, c_void_p, c_void_p]),
+    "vx_bn_bwd_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vx_bn_bwd_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vx_boxes_overlap_bev": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     "vx_nms_workspace_bytes": (c_size_t, [c_int32]),
     "vx_nms_bev": (c_int32, [c_void_p, c_int32, ctypes.c_float, c_int32, c_void_p, c_i64p, c_void_p, c_size_t,

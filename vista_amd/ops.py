@@ -413,3 +413,115 @@ def conv_wgrad(features, grad_out, rb, weight_shape):
                                  _ptr(num), rb.kvol, _ptr(dw), _DT[features.dtype], _ptr(ws), wsb, _stream())
     L.check(rc, "vx_spconv_wgrad")
     return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# train-mode BatchNorm1d (+ residual + ReLU) over sparse features
+# ------------------------------------------------------------------------------------------------
+def bn_supported(c):
+    """Widths the fused BatchNorm kernels take: a power of two in [8, 512]."""
+    return 8 <= c <= 512 and (c & (c - 1)) == 0
+
+
+def _bn_check(x, name):
+    _need_gpu(x, name)
+    if x.dtype != torch.float32 or x.dim() != 2 or not bn_supported(x.shape[1]):
+        raise ValueError(f"{name} must be float32 [n, c] with c a power of two in [8, 512], got {tuple(x.shape)} {x.dtype}")
+    return x.contiguous()
+
+
+def bn_stats(x):
+    """-> f64[2c+1] = (sum x, sum x^2 per channel, n). Under SyncBN the caller all-reduces this tensor."""
+    x = _bn_check(x, "x")
+    n, c = x.shape
+    sums = torch.empty((2 * c + 1,), dtype=torch.float64, device=x.device)
+    lib = L.lib()
+    wsb = lib.vx_bn_workspace_bytes(c)
+    ws = _ws(wsb, x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.vx_bn_stats(_ptr(x), n, c, _ptr(sums), _ptr(ws), wsb, _stream())
+    L.check(rc, "vx_bn_stats")
+    return sums
+
+
+def bn_finalize(sums, c, eps, momentum, running_mean=None, running_var=None):
+    """sums f64[2c+1] -> (mean, invstd) f32[c]; updates the running statistics in place when given."""
+    _need_gpu(sums, "sums")
+    if sums.dtype != torch.float64 or sums.numel() != 2 * c + 1 or not sums.is_contiguous():
+        raise ValueError("sums must be a contiguous float64 tensor of 2c+1 elements")
+    for t in (running_mean, running_var):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != c or not t.is_cuda or not t.is_contiguous()):
+            raise ValueError("running statistics must be contiguous float32 CUDA tensors of length c")
+    mean = torch.empty((c,), dtype=torch.float32, device=sums.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=sums.device)
+    with torch.cuda.device(sums.device):
+        rc = L.lib().vx_bn_finalize(_ptr(sums), c, float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                                    _ptr(mean), _ptr(invstd), _stream())
+    L.check(rc, "vx_bn_finalize")
+    return mean, invstd
+
+
+def _bn_vec(t, c, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or t.numel() != c:
+        raise ValueError(f"{name} must be a float32 CUDA tensor of length c")
+    return t.contiguous()
+
+
+def bn_apply(x, mean, invstd, gamma=None, beta=None, residual=None, relu=False):
+    """-> (y, mask): y = relu?((x - mean) * invstd * gamma + beta + residual?); mask uint8[n*c/8] (one bit per
+    element, y > 0) when relu else None."""
+    x = _bn_check(x, "x")
+    n, c = x.shape
+    mean, invstd = _bn_vec(mean, c, "mean"), _bn_vec(invstd, c, "invstd")
+    gamma, beta = _bn_vec(gamma, c, "gamma"), _bn_vec(beta, c, "beta")
+    if residual is not None:
+        residual = _bn_check(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("residual must match x")
+    y = torch.empty_like(x)
+    mask = torch.empty((n * c // 8,), dtype=torch.uint8, device=x.device) if relu else None
+    with torch.cuda.device(x.device):
+        rc = L.lib().vx_bn_apply(_ptr(x), n, c, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual),
+                                 1 if relu else 0, _ptr(y), _ptr(mask), _stream())
+    L.check(rc, "vx_bn_apply")
+    return y, mask
+
+
+def bn_bwd_reduce(dy, x, mask, mean, invstd):
+    """-> (sums f64[2c] = (sum g, sum g*xhat), param_grads f32[2c] = (d beta, d gamma) of this rank)."""
+    dy, x = _bn_check(dy, "dy"), _bn_check(x, "x")
+    if dy.shape != x.shape:
+        raise ValueError("dy must match x")
+    n, c = x.shape
+    if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != n * c // 8 or not mask.is_cuda):
+        raise ValueError("mask must be the uint8[n*c/8] tensor bn_apply returned")
+    sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+    pg = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    lib = L.lib()
+    wsb = lib.vx_bn_workspace_bytes(c)
+    ws = _ws(wsb, x.device)
+    mean, invstd = _bn_vec(mean, c, "mean"), _bn_vec(invstd, c, "invstd")
+    with torch.cuda.device(x.device):
+        rc = lib.vx_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mask), n, c, _ptr(mean), _ptr(invstd), _ptr(sums), _ptr(pg),
+                                  _ptr(ws), wsb, _stream())
+    L.check(rc, "vx_bn_bwd_reduce")
+    return sums, pg
+
+
+def bn_bwd_apply(dy, x, mask, mean, invstd, gamma, sums, count, want_dres=False):
+    """-> (dx, dres | None). sums f64[2c] (all-reduced under SyncBN), count f64[1] = total rows."""
+    dy, x = _bn_check(dy, "dy"), _bn_check(x, "x")
+    n, c = x.shape
+    if sums.dtype != torch.float64 or sums.numel() != 2 * c or count.dtype != torch.float64 or count.numel() != 1:
+        raise ValueError("sums must be float64[2c] and count float64[1]")
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    mean, invstd, gamma = _bn_vec(mean, c, "mean"), _bn_vec(invstd, c, "invstd"), _bn_vec(gamma, c, "gamma")
+    sums, count = sums.contiguous(), count.contiguous()
+    with torch.cuda.device(x.device):
+        rc = L.lib().vx_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(mask), n, c, _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                     _ptr(sums), _ptr(count), _ptr(dx), _ptr(dres), _stream())
+    L.check(rc, "vx_bn_bwd_apply")
+    return dx, dres

@@ -3,6 +3,7 @@
   shard_frames           det3d/datasets/loader/sampler.py:74-96 (DistributedSampler, shuffle=False: rank::world)
   allreduce_grads_flat   det3d/core/utils/dist_utils.py:7-41 (_allreduce_coalesced: one flat bucket per dtype)
   wrap_sync_bn           det3d/torchie/apis/train.py:301 (SyncBatchNorm.convert_sync_batchnorm)
+  fused_bn.fuse_for_training  the same statistics exchange inside the fused BatchNorm+add+ReLU kernels (default)
   train_step             det3d/core/utils/dist_utils.py:50-56 + trainer loop (zero_grad, backward, step)
 
 One process per GPU; the only collective on the data path is the gradient all-reduce (RCCL over xGMI
@@ -77,7 +78,11 @@ def bench_train(a, dev, rank, world, dist):
     grid = grid_size(rg, vs).tolist()
     net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
                                        backbone_state_dict("SpMiddleResNetFHD")).to(dev).train()
-    net = wrap_sync_bn(net, world, dist)
+    if getattr(a, "torch_bn", False):
+        net = wrap_sync_bn(net, world, dist)          # stock torch BatchNorm1d / SyncBatchNorm + ReLU + add kernels
+    else:
+        from .fused_bn import fuse_for_training      # libvx BatchNorm(+add+ReLU) kernels; global statistics when world > 1
+        net = fuse_for_training(net, sync=world > 1)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     frames = [torch.from_numpy(lidar_cloud(seed=rank * a.batch + b, sweeps=10)).to(dev) for b in range(a.batch)]
 
@@ -113,7 +118,9 @@ def bench_train(a, dev, rank, world, dist):
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{a.geometry} 10-sweep synthetic frames, batch {a.batch}/GPU, DP training step "
-                               "(BASELINE.json configs[4]), loss = mean(out^2), SyncBN when >1 GPU",
+                               "(BASELINE.json configs[4]), loss = mean(out^2), SyncBN when >1 GPU, "
+                               + ("torch BatchNorm/ReLU kernels" if getattr(a, "torch_bn", False) else
+                                  "fused libvx BatchNorm+add+ReLU kernels"),
                    "frames_per_gpu": a.batch, "parallelism": f"dp{world}", "grad_bucket_bytes": 4 * nparam},
         "final_loss": float(loss.item()),
     }
