@@ -72,22 +72,25 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_partial(const float* __re
   block_combine(s, q, c, c8, part);
 }
 
-// sums[j] = sum over blocks of part[g][j], fixed order; optional fp32 copy (parameter gradients)
+// sums[j] = sum over blocks of part[g][j], fixed order; optional fp32 copy (parameter gradients).
+// One workgroup per 32 columns: 32 x 32 threads, thread (col, split) adds rows split, split + 32, ... (256-byte
+// coalesced row segments), then the 32 splits of a column are added in order.
 __global__ __launch_bounds__(kBnFinalThreads) void bn_reduce_final(const double* __restrict__ part, int blocks, int c2,
                                                                    double* __restrict__ sums, float* __restrict__ sums_f32) {
-  __shared__ double sh[kBnFinalThreads];
-  const int split = kBnFinalThreads / c2;   // >= 1 (c2 <= 1024 checked by the host)
-  const int j = threadIdx.x % c2, sidx = threadIdx.x / c2;
+  __shared__ double sh[32][33];
+  const int col = threadIdx.x & 31, split = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + col;
   double acc = 0.0;
-  if (sidx < split)
-    for (int g = sidx; g < blocks; g += split) acc += part[(long long)g * c2 + j];
-  sh[threadIdx.x] = acc;
+  if (j < c2)
+    for (int g = split; g < blocks; g += 32) acc += part[(long long)g * c2 + j];
+  sh[split][col] = acc;
   __syncthreads();
-  if ((int)threadIdx.x < c2) {
+  if (split == 0 && j < c2) {
     double t = 0.0;
-    for (int m = 0; m < split; ++m) t += sh[m * c2 + threadIdx.x];
-    sums[threadIdx.x] = t;
-    if (sums_f32) sums_f32[threadIdx.x] = (float)t;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) t += sh[m][col];
+    sums[j] = t;
+    if (sums_f32) sums_f32[j] = (float)t;
   }
 }
 
@@ -252,7 +255,7 @@ int32_t vx_bn_stats(const float* d_x, int64_t n, int32_t c, double* d_sums, void
   double* part = (double*)d_workspace;
   bn_stats_partial<<<blocks, kBnThreads, 0, s>>>(d_x, items, c, c / 8, part);
   VX_LAUNCH_CHECK();
-  bn_reduce_final<<<1, kBnFinalThreads, 0, s>>>(part, blocks, 2 * c, d_sums, nullptr);
+  bn_reduce_final<<<(2 * c + 31) / 32, kBnFinalThreads, 0, s>>>(part, blocks, 2 * c, d_sums, nullptr);
   VX_LAUNCH_CHECK();
   bn_set_count<<<1, 64, 0, s>>>(d_sums + 2 * c, (double)n);
   VX_LAUNCH_CHECK();
@@ -309,7 +312,7 @@ int32_t vx_bn_bwd_reduce(const float* d_dy, const float* d_x, const uint8_t* d_m
   double* part = (double*)d_workspace;
   bn_bwd_partial<<<blocks, kBnThreads, 0, s>>>(d_dy, d_x, d_mask, items, c, c / 8, d_mean, d_invstd, part);
   VX_LAUNCH_CHECK();
-  bn_reduce_final<<<1, kBnFinalThreads, 0, s>>>(part, blocks, 2 * c, d_sums, d_param_grads);
+  bn_reduce_final<<<(2 * c + 31) / 32, kBnFinalThreads, 0, s>>>(part, blocks, 2 * c, d_sums, d_param_grads);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }
