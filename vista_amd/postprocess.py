@@ -98,12 +98,18 @@ def merge_double_flip(box_coder, box_preds, cls_preds):
     return scores, reg
 
 
-def get_task_detections(test_cfg, scores, boxes, meta_list=None):
+def _range_index(box, rng):
+    """Rows of box [n, >=3] whose centre lies inside rng = (x0, y0, z0, x1, y1, z1); one host sync."""
+    return ((box[:, :3] >= rng[:3]).all(1) & (box[:, :3] <= rng[3:]).all(1)).nonzero().squeeze(1)
+
+
+def get_task_detections(test_cfg, scores, boxes, meta_list=None, range_filter=True):
     """Per frame: best class per cell, score threshold, rotated NMS (pre/post max sizes), centre range filter.
-    scores [b, N, ncls] (already sigmoid), boxes [b, N, 9]."""
+    scores [b, N, ncls] (already sigmoid), boxes [b, N, 9]. Every data-dependent selection is ONE nonzero() (one host
+    sync) followed by index_selects; range_filter=False leaves the (per-box) centre range filter to the caller."""
     test_cfg = AttrDict(test_cfg)
     rng = test_cfg.post_center_limit_range
-    rng = boxes.new_tensor(rng) if rng is not None and len(rng) > 0 else None
+    rng = boxes.new_tensor(rng).float() if range_filter and rng is not None and len(rng) > 0 else None
     meta_list = meta_list or [None] * boxes.shape[0]
     out = []
     for box, sc, meta in zip(boxes, scores, meta_list):
@@ -113,7 +119,7 @@ def get_task_detections(test_cfg, scores, boxes, meta_list=None):
         else:
             top, labels = torch.max(sc, dim=-1)
         if test_cfg.score_threshold > 0.0:
-            keep = top >= top.new_tensor([test_cfg.score_threshold])
+            keep = (top >= test_cfg.score_threshold).nonzero().squeeze(1)
             top, box, labels = top[keep], box[keep], labels[keep]
         if top.shape[0] != 0:
             sel = rotate_nms_pcdet(boxes3d_to_bevboxes_lidar_torch(box), top, thresh=test_cfg.nms.nms_iou_threshold,
@@ -121,7 +127,7 @@ def get_task_detections(test_cfg, scores, boxes, meta_list=None):
                                    post_max_size=test_cfg.nms.nms_post_max_size)
             box, top, labels = box[sel], top[sel], labels[sel]
         if box.shape[0] != 0 and rng is not None:
-            m = (box[:, :3] >= rng[:3]).all(1) & (box[:, :3] <= rng[3:]).all(1)
+            m = _range_index(box, rng)
             box, top, labels = box[m], top[m], labels[m]
         out.append({"box3d_lidar": box, "scores": top, "label_preds": labels, "metadata": meta})
     return out
@@ -143,14 +149,21 @@ def predict(preds_dicts, test_cfg, num_classes, box_coder, metadata=None):
             scores = cls.sigmoid().reshape(B, H * W, -1)
             reg = decode_boxes(box_coder, box.reshape(B, H * W, C), W, H)
             meta = metadata
-        rets.append(get_task_detections(test_cfg, scores, reg, meta))
+        # the centre range filter acts on each box alone: it is applied once per frame below, on the concatenated
+        # tasks, instead of once per (task, frame) -- same detections, a sixth of the host syncs
+        rets.append(get_task_detections(test_cfg, scores, reg, meta, range_filter=False))
+    rng = test_cfg.post_center_limit_range
     out = []
     for i in range(len(rets[0])):
         flag, labels = 0, []
         for j, n in enumerate(num_classes):
             labels.append(rets[j][i]["label_preds"] + flag)
             flag += n
-        out.append({"box3d_lidar": torch.cat([r[i]["box3d_lidar"] for r in rets]),
-                    "scores": torch.cat([r[i]["scores"] for r in rets]),
-                    "label_preds": torch.cat(labels), "metadata": rets[0][i]["metadata"]})
+        box = torch.cat([r[i]["box3d_lidar"] for r in rets])
+        top = torch.cat([r[i]["scores"] for r in rets])
+        labels = torch.cat(labels)
+        if box.shape[0] != 0 and rng is not None and len(rng) > 0:
+            m = _range_index(box, box.new_tensor(rng))
+            box, top, labels = box[m], top[m], labels[m]
+        out.append({"box3d_lidar": box, "scores": top, "label_preds": labels, "metadata": rets[0][i]["metadata"]})
     return out
