@@ -175,3 +175,38 @@ def test_registries_and_build_from_cfg():
         r.register_module(A)
     with pytest.raises(TypeError):
         r.register_module(lambda: 0)
+
+
+def test_fuse_for_training_keeps_parameters_and_keys():
+    """vista_amd.fused_bn.fuse_for_training (host logic only): the rewritten backbone has the same state_dict keys,
+    shares the original parameter and buffer tensors, holds 21 fused norms (9 of them taking the block's residual)
+    and no stand-alone ReLU after a fused norm; in eval mode a fused norm is nn.BatchNorm1d + ReLU."""
+    import torch
+    from vista_amd import models
+    from vista_amd.fused_bn import FusedBatchNorm1d, FusedSparseBasicBlock, fuse_for_training
+    net = models.SpMiddleResNetFHD(num_input_features=5)
+    keys = list(net.state_dict().keys())
+    params = {k: v.data_ptr() for k, v in net.state_dict().items()}
+    fuse_for_training(net)
+    assert list(net.state_dict().keys()) == keys
+    assert {k: v.data_ptr() for k, v in net.state_dict().items()} == params
+    fused = [m for m in net.modules() if isinstance(m, FusedBatchNorm1d)]
+    assert len(fused) == 21 and all(m.relu for m in fused)
+    assert sum(isinstance(m, FusedSparseBasicBlock) for m in net.modules()) == 8
+    assert not any(type(m) is torch.nn.BatchNorm1d for m in net.modules())
+    seq = list(net.middle_conv._modules.values())
+    for a, b in zip(seq, seq[1:]):
+        if isinstance(a, FusedBatchNorm1d):
+            assert isinstance(b, torch.nn.Identity)
+    # fusing twice changes nothing
+    fuse_for_training(net)
+    assert list(net.state_dict().keys()) == keys
+    bn = torch.nn.BatchNorm1d(16).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    f = FusedBatchNorm1d.from_bn(bn, relu=True)
+    x, r = torch.randn(10, 16), torch.randn(10, 16)
+    assert torch.equal(f(x, residual=r), torch.relu(bn(x) + r))
+    with pytest.raises(ValueError):
+        FusedBatchNorm1d.from_bn(torch.nn.BatchNorm1d(16, affine=False))
