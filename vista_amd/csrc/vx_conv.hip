@@ -832,6 +832,242 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
   }
 }
 
+// 16-pair tasks (fp32, Cin = 64): the same per-offset compaction with three changes, each from a timing-only ablation of
+// the 32-pair NS = 2 form on the FHD 64->64 layer (2.85 ms: MFMAs 1.1 ms, LDS accumulate 0.9, compaction 0.7, floor 0.5,
+// gathers 0.15 -- nearly additive, i.e. the phases ran one after the other behind the per-offset barrier):
+//  * a wave takes 16 pairs and ALL Cout channels on v_mfma_f32_16x16x4_f32 (same flops per cycle as 32x32x2) instead of
+//    two waves sharing a 32-pair group by output-channel halves: every input row is gathered once, four lanes share a row
+//    (64 bytes each), and the pair count is rounded up to 16 instead of 32;
+//  * ONE producer wave (the last: it has a task of its own only when more than 16 (WAVES - 1) pairs are present) ranks the
+//    tile's entries two offsets ahead and publishes the compacted (input row, output row) list in LDS; the other waves
+//    read their 16 slots (one ds_read_b64 per lane) instead of every wave ranking all 256 entries with ballots and
+//    ds_permutes, and only the producer reads the neighbour table;
+//  * the += of offset k's products into the LDS accumulators is deferred into offset k + 1's MFMA stream (read issued
+//    before a 16-MFMA group, add + write after it), so its LDS latency hides under matrix work. Offsets are still
+//    separated by one barrier: within an offset an output row belongs to one pair, hence one wave, and the deferred
+//    accumulate of offset k finishes before the barrier that precedes any accumulate of offset k + 1.
+// Operands: B (gathered rows): lane (n = lane & 15, kq = lane >> 4) holds channels [16 kq, 16 kq + 16) of pair n; the
+// reduction index is permuted accordingly (MFMA step (q, j) sums channels 16 kq + 4 q + j over kq); A: the W fragment
+// from LDS with the same permutation; D: lane (n, kq) holds output channels 16 t + 4 kq + {0..3} of pair n, 16 contiguous
+// bytes of that pair's accumulator row.
+#ifndef VX_CB16
+#define VX_CB16 1
+#endif
+template <int CIN, int COUT_PAD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a) {
+  constexpr int kCbRows = 16 * WAVES, kCbThreads = 64 * WAVES;
+  static_assert(kCbRows % 64 == 0 && COUT_PAD % 16 == 0 && CIN % 16 == 0, "tile shape");
+  constexpr int NE = kCbRows / 64;                   // neighbour entries per producer lane
+  constexpr int NT = COUT_PAD / 16;                  // 16-channel output tiles (a wave computes all of them)
+  constexpr int QR = CIN * 4 / 16;                   // 16-byte quads per row
+  constexpr int QK = QR / 4;                         // quads per lane (a quarter of a row)
+  static_assert(NT == QK, "one deferred accumulator tile per MFMA group");
+  constexpr int W_ROW = CIN * 4 + 16;                // padded W row (bytes)
+  constexpr int W_Q = COUT_PAD * QR;
+  constexpr int W_LD = (W_Q + kCbThreads - 1) / kCbThreads;
+  constexpr int ACC_LD = COUT_PAD + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sAcc = reinterpret_cast<float*>(smem_raw);                       // [(R + 1)][ACC_LD], row R = dump
+  char* sWb = smem_raw + (kCbRows + 1) * ACC_LD * 4;                      // 2 x [COUT_PAD][W_ROW]
+  int2* sList = reinterpret_cast<int2*>(sWb + 2 * COUT_PAD * W_ROW);      // 2 x [R] (input row + 1, output row + 1)
+  int* sCnt = reinterpret_cast<int*>(sList + 2 * kCbRows);                // 2 pair counts
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, kq = lane >> 4;
+  const bool producer = wave == WAVES - 1;
+  const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
+  const int col0 = blockIdx.y * COUT_PAD;
+  const char* in = reinterpret_cast<const char*>(a.in);
+  const char* wgt = reinterpret_cast<const char*>(a.w);
+  const char* zero = reinterpret_cast<const char*>(a.zero);
+
+  for (int e = threadIdx.x; e < (kCbRows + 1) * ACC_LD; e += kCbThreads) sAcc[e] = 0.0f;
+
+  // ---- producer: neighbour entries of offset ks for tile rows lane, lane + 64, ... and their compaction ----
+  auto load_nbr = [&](int ks, int (&e)[NE]) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) e[j] = -1;
+    if (ks < a.kvol) {
+      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
+      const int* t = a.nbr + (long long)krow * a.ld + row0;
+#pragma unroll
+      for (int j = 0; j < NE; ++j)
+        if (row0 + lane + 64 * j < a.n_out) e[j] = t[lane + 64 * j];
+    }
+  };
+  auto publish = [&](const int (&e)[NE], int lb) {
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const unsigned long long m = __ballot(e[j] >= 0);
+      const int d = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+      if (e[j] >= 0) sList[lb * kCbRows + d] = make_int2(e[j] + 1, lane + 64 * j + 1);
+      base += __popcll(m);
+    }
+    if (lane == 0) sCnt[lb] = base;
+  };
+  // ---- consumers: this wave's 16 slots of a published list (slots past the count read as empty) ----
+  auto fetch_pairs = [&](int lb, int& idx_p1, int& row_p1) {
+    const int cnt = sCnt[lb];
+    const int slot = 16 * wave + n16;
+    const int2 v = sList[lb * kCbRows + slot];
+    idx_p1 = slot < cnt ? v.x : 0;
+    row_p1 = slot < cnt ? v.y : 0;
+    return cnt;
+  };
+  auto load_a = [&](int idx_p1, f32x4(&dst)[QK]) {
+    const char* src = idx_p1 > 0 ? in + ((long long)(idx_p1 - 1) * CIN + kq * (CIN / 4)) * 4 : zero;
+#pragma unroll
+    for (int q = 0; q < QK; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + 16 * q);
+  };
+  f32x4 rw[W_LD];
+  auto load_w = [&](int ks) {
+    const int kk = ks < a.kvol ? ks : a.kvol - 1;
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kCbThreads + (int)threadIdx.x;
+      const int oc = e / QR, q = e % QR;
+      const int goc = col0 + oc;
+      const bool ok = e < W_Q && goc < a.cout;
+      const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * 4 + 16 * q : zero;
+      rw[t] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_w = [&](int buf) {
+    char* sW = sWb + buf * COUT_PAD * W_ROW;
+#pragma unroll
+    for (int t = 0; t < W_LD; ++t) {
+      const int e = t * kCbThreads + (int)threadIdx.x;
+      const int oc = e / QR, q = e % QR;
+      if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
+    }
+  };
+  auto acc_row = [&](int row_p1) {   // empty slots add zeros to the dump row
+    return sAcc + (row_p1 > 0 ? row_p1 - 1 : kCbRows) * ACC_LD + 4 * kq;
+  };
+  // pending products of the previous offset (this wave's 16 pairs x Cout), added to LDS during the next MFMA stream
+  f32x4 dP[NT];
+  int rowP = 0;
+  bool haveP = false;
+  auto flush_pending = [&]() {
+    float* arow = acc_row(rowP);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4* dst = reinterpret_cast<f32x4*>(arow + t * 16);
+      *dst = *dst + dP[t];
+    }
+  };
+  auto mfma_group = [&](int buf, const f32x4(&ra)[QK], int row_p1) {
+    f32x4 d[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) d[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const char* pb = sWb + buf * COUT_PAD * W_ROW + n16 * W_ROW + kq * CIN;   // kq * (CIN / 4) floats
+    float* arowP = acc_row(rowP);
+#pragma unroll
+    for (int q = 0; q < QK; ++q) {
+      f32x4 old = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (haveP) old = *reinterpret_cast<const f32x4*>(arowP + q * 16);
+      f32x4 bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 16 * W_ROW + 16 * q);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].x, ra[q].x, d[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].y, ra[q].y, d[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].z, ra[q].z, d[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, ra[q].w, d[t], 0, 0, 0);
+      if (haveP) *reinterpret_cast<f32x4*>(arowP + q * 16) = old + dP[q];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dP[t] = d[t];
+    rowP = row_p1;
+    haveP = true;
+  };
+
+  // ---- prologue: lists of offsets 0 and 1, entries of offset 2 in flight; first gather and W ----
+  int pn[NE];
+  if (producer) {
+    int e0[NE], e1[NE];
+    load_nbr(0, e0);
+    load_nbr(1, e1);
+    load_nbr(2, pn);
+    publish(e0, 0);
+    publish(e1, 1);
+  }
+  __syncthreads();
+  int idxA, rowA, idxB, rowB;
+  f32x4 raA[QK], raB[QK];
+  int cntA = fetch_pairs(0, idxA, rowA);
+  load_w(0);
+  load_a(idxA, raA);
+  store_w(0);
+  __syncthreads();
+  // one trip = two offsets (ping-pong register sets)
+  auto step = [&](int k, int buf, int cnt_cur, const f32x4(&cur)[QK], int row_cur, int& cnt_nxt, f32x4(&nxt)[QK],
+                  int& idx_nxt, int& row_nxt) {
+    if (producer) {                       // list of offset k + 2 into the buffer offset k's list has left
+      publish(pn, k & 1);
+      load_nbr(k + 3, pn);
+    }
+    cnt_nxt = fetch_pairs((k + 1) & 1, idx_nxt, row_nxt);
+    load_w(k + 1);
+    load_a(idx_nxt, nxt);
+    if (16 * wave < cnt_cur) {
+      mfma_group(buf, cur, row_cur);
+    } else if (haveP) {
+      flush_pending();
+      haveP = false;
+    }
+    store_w(buf ^ 1);
+    __syncthreads();
+  };
+  int cntB = 0;
+  for (int k = 0; k < a.kvol; k += 2) {
+    step(k, 0, cntA, raA, rowA, cntB, raB, idxB, rowB);
+    if (k + 1 >= a.kvol) break;
+    step(k + 1, 1, cntB, raB, rowB, cntA, raA, idxA, rowA);
+  }
+  if (haveP) flush_pending();
+  __syncthreads();
+
+  // ---- epilogue: bias, per-channel affine (folded BatchNorm), residual, ReLU; coalesced rows ----
+  constexpr int CQ = COUT_PAD / 4;
+  for (int e = threadIdx.x; e < kCbRows * CQ; e += kCbThreads) {
+    const int rr = e / CQ, c = col0 + 4 * (e % CQ);
+    const long long row = row0 + rr;
+    if (row >= a.n_out) continue;
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(sAcc + rr * ACC_LD + 4 * (e % CQ));
+    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = c + j;
+      if (col >= a.cout) continue;
+      float v = vv[j] + (a.bias ? a.bias[col] : 0.0f);
+      if (a.scale || a.shift) v = v * (a.scale ? a.scale[col] : 1.0f) + (a.shift ? a.shift[col] : 0.0f);
+      if (a.residual) v += a.residual[row * a.cout + col];
+      if (a.relu) v = fmaxf(v, 0.0f);
+      a.out[row * a.cout + col] = v;
+    }
+  }
+}
+
+template <int CIN, int COUT_PAD, int WAVES>
+int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
+  constexpr int R = 16 * WAVES;
+  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * 4 + 16) +
+                         (size_t)2 * R * sizeof(int2) + 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(((R + 1) * (COUT_PAD + 4) * 4) % 16 == 0 && (2 * COUT_PAD * (CIN * 4 + 16)) % 8 == 0, "LDS alignment");
+  auto kern = spconv_cb16<CIN, COUT_PAD, WAVES>;
+  VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
+  kern<<<grid, 64 * WAVES, lds, stream>>>(a);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
 template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1>
 int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
   constexpr int R = 32 * WAVES / NS;
@@ -858,7 +1094,8 @@ int32_t dispatch_cb_t(const ConvArgs& a, hipStream_t s) {
     case 32: return wide ? launch_cb<T, 32, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 32, 32, VX_CB_WAVES>(a, s);
     case 64:
       if constexpr (sizeof(T) == 4)
-        return wide ? launch_cb<T, 64, 64, VX_CB_WAVES_64, VX_CB_NS_64>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
+        return wide ? (VX_CB16 ? launch_cb16<64, 64, 16>(a, s) : launch_cb<T, 64, 64, VX_CB_WAVES_64, VX_CB_NS_64>(a, s))
+                    : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
       else
         return wide ? launch_cb<T, 64, 64, VX_CB_WAVES>(a, s) : launch_cb<T, 64, 32, VX_CB_WAVES>(a, s);
     case 128:
