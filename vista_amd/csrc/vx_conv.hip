@@ -967,17 +967,21 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a) {
     for (int q = 0; q < QK; ++q) {
       f32x4 old = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (haveP) old = *reinterpret_cast<const f32x4*>(arowP + q * 16);
-      f32x4 bv[NT];
+      // W fragments two tiles at a time: the kernel sits at the 128-VGPR cap of a 1024-thread workgroup
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + t * 16 * W_ROW + 16 * q);
+      for (int t0 = 0; t0 < NT; t0 += 2) {
+        f32x4 bv[2];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].x, ra[q].x, d[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) bv[t] = *reinterpret_cast<const f32x4*>(pb + (t0 + t) * 16 * W_ROW + 16 * q);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].y, ra[q].y, d[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) d[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].x, ra[q].x, d[t0 + t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].z, ra[q].z, d[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) d[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].y, ra[q].y, d[t0 + t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, ra[q].w, d[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) d[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].z, ra[q].z, d[t0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) d[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, ra[q].w, d[t0 + t], 0, 0, 0);
+      }
       if (haveP) *reinterpret_cast<f32x4*>(arowP + q * 16) = old + dP[q];
     }
 #pragma unroll
