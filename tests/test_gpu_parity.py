@@ -582,10 +582,15 @@ def test_frame_pipeline_bitwise_equals_single_batch(dev):
 
 
 @pytest.mark.parametrize("n_sites,ksize,cin,cout", [(7, 3, 16, 16), (33, 1, 32, 32), (129, 3, 64, 64), (300, 5, 16, 32),
-                                                     (257, 3, 64, 128), (1, 3, 32, 64)])
+                                                     (257, 3, 64, 128), (1, 3, 32, 64),
+                                                     # the 16-pair kernel (fp32 Cin = 64, Cout > 32): one offset only, 125
+                                                     # offsets, a single row, ragged multi-tile grids with Cout tiled over y
+                                                     (5, 1, 64, 64), (40, 5, 64, 64), (1, 3, 64, 128), (700, 3, 64, 64),
+                                                     (513, 1, 64, 128)])
 def test_compaction_kernel_edge_shapes(n_sites, ksize, cin, cout, dev):
-    """Per-offset compaction kernel on tiny / ragged tiles, 1x1x1 and 5x5x5 kernels (125 offsets), Cout tiled
-    over blockIdx.y, forward and dgrad, against the oracle and bitwise against itself on a second run."""
+    """Per-offset compaction kernels (spconv_cb and, for fp32 Cin = 64 with Cout > 32, spconv_cb16) on tiny / ragged tiles,
+    1x1x1 and 5x5x5 kernels (125 offsets), Cout tiled over blockIdx.y, forward and dgrad, against the oracle and bitwise
+    against itself on a second run."""
     from oracle import spconv_oracle as so
     from vista_amd import ops
     rng = np.random.default_rng(n_sites * 31 + ksize)
