@@ -56,3 +56,45 @@ def test_flat_allreduce_equals_single_process_gradient():
     for _, _, _, flat in res:
         assert torch.allclose(flat, ref, rtol=1e-5, atol=1e-6)
     assert torch.equal(res[0][3], res[1][3])      # both ranks hold identical averaged gradients
+
+
+def _bn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vista_amd.fused_bn import _all_reduce_sum
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1000, 16, generator=g, dtype=torch.float64) * 2 + 0.5
+    cut = 300                                   # uneven shards, as frames hold different voxel counts
+    mine = x[:cut] if rank == 0 else x[cut:]
+    # the vector vx_bn_stats produces on each rank: (sum x, sum x^2 per channel, row count)
+    sums = torch.cat([mine.sum(0), (mine * mine).sum(0), torch.tensor([float(mine.shape[0])], dtype=torch.float64)])
+    _all_reduce_sum(sums, None)
+    q.put((rank, sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_sum_exchange_gives_global_statistics():
+    """The one collective of FusedBatchNorm1d(sync=True): after _all_reduce_sum every rank holds the sums and the row
+    count of ALL rows, from which vx_bn_finalize takes the batch mean / variance (SyncBatchNorm, train.py:301)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1000, 16, generator=g, dtype=torch.float64) * 2 + 0.5
+    assert torch.equal(res[0][1], res[1][1])
+    s = res[0][1]
+    n = float(s[32])
+    assert n == 1000.0
+    mean, var = s[:16] / n, s[16:32] / n - (s[:16] / n) ** 2
+    assert torch.allclose(mean, x.mean(0), rtol=1e-12, atol=1e-12)
+    assert torch.allclose(var, x.var(0, unbiased=False), rtol=1e-10, atol=1e-12)
