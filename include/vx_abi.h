@@ -40,8 +40,9 @@ extern "C" {
 /* kernel choice of vx_spconv_fwd: fp32 layers with cin in {16,32,64} and cout <= 128 run the per-offset
    compaction kernel unless this flag asks for the row-stationary kernels (A/B timing, tests) */
 #define VX_CONV_NO_COMPACT 0x100
-/* the row-stationary kernel splits its last partial round of row tiles over output-column halves
-   (same sums, bitwise identical output); this flag launches the plain grid instead (A/B timing, tests) */
+/* the row-stationary kernel splits its last partial round of row tiles over output-column halves, and the
+   16-pair compaction kernel (fp32 cin = 64) runs its last partial round as a second launch on half-height tiles
+   (same sums, bitwise identical output); this flag launches the plain grids instead (A/B timing, tests) */
 #define VX_CONV_NO_SPLIT_TAIL 0x200
 
 int32_t vx_version(void);

@@ -538,6 +538,30 @@ def test_conv_fwd_split_tail_bitwise(cin, n_sites, dtype, dev):
     assert float(got.float().abs().max()) > 0
 
 
+@pytest.mark.parametrize("n_sites", [66000, 70000, 90000])
+def test_compaction_kernel_half_height_tail_bitwise(n_sites, dev):
+    """spconv_cb16's tail launch (the last partial round of 256-row tiles re-tiled at 128 rows in a second launch) is
+    bitwise equal to the single launch: 66000 / 70000 / 90000 rows = one full round of 256 tiles + 2 / 18 / 96 tail
+    tiles (the last one ragged). Forward with the full epilogue, and dgrad."""
+    from vista_amd import ops
+    rng = np.random.default_rng(n_sites)
+    shape = [5, 200, 200]
+    coords = random_sites(rng, 1, shape, n_sites)
+    n = coords.shape[0]
+    x = torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32)).to(dev)
+    wt = torch.from_numpy((rng.normal(size=(64, 3, 3, 3, 64)) / np.sqrt(27 * 64)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.normal(size=(64,)).astype(np.float32)).to(dev)
+    res = torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32)).to(dev)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 1, shape, 3)
+    got = ops.conv_fwd(x, wt, rb, bias=b, residual=res, relu=True)
+    base = ops.conv_fwd(x, wt, rb, bias=b, residual=res, relu=True, split_tail=False)
+    assert torch.equal(got, base)
+    assert float(got.abs().max()) > 0
+    # against the row-stationary kernel family: same values to fp32 rounding
+    other = ops.conv_fwd(x, wt, rb, bias=b, residual=res, relu=True, compact=False)
+    assert float((got - other).abs().max()) <= 1e-4 * float(other.abs().max())
+
+
 def test_voxelize_batch_equals_per_frame(dev):
     """One batched launch sequence == per-frame calls + collate (bit-exact, incl. the mean)."""
     from vista_amd import ops

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 #define VX_CB16 1
 #endif
 template <int CIN, int COUT_PAD, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long row_base) {
   constexpr int kCbRows = 16 * WAVES, kCbThreads = 64 * WAVES;
   static_assert(kCbRows % 64 == 0 && COUT_PAD % 16 == 0 && CIN % 16 == 0, "tile shape");
   constexpr int NE = kCbRows / 64;                   // neighbour entries per producer lane
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, kq = lane >> 4;
   const bool producer = wave == WAVES - 1;
-  const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
+  const long long row0 = row_base + (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
   const int col0 = blockIdx.y * COUT_PAD;
   const char* in = reinterpret_cast<const char*>(a.in);
   const char* wgt = reinterpret_cast<const char*>(a.w);
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a) {
 }
 
 template <int CIN, int COUT_PAD, int WAVES>
-int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
+int32_t launch_cb16_rows(const ConvArgs& a, long long row_base, long long n_tiles, hipStream_t stream) {
   constexpr int R = 16 * WAVES;
   constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * 4 + 16) +
                          (size_t)2 * R * sizeof(int2) + 16;
@@ -1066,10 +1066,31 @@ int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
   static_assert(((R + 1) * (COUT_PAD + 4) * 4) % 16 == 0 && (2 * COUT_PAD * (CIN * 4 + 16)) % 8 == 0, "LDS alignment");
   auto kern = spconv_cb16<CIN, COUT_PAD, WAVES>;
   VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
-  kern<<<grid, 64 * WAVES, lds, stream>>>(a);
+  dim3 grid((unsigned)n_tiles, (unsigned)vx_cdiv(a.cout, COUT_PAD));
+  kern<<<grid, 64 * WAVES, lds, stream>>>(a, row_base);
   VX_LAUNCH_CHECK();
   return VX_OK;
+}
+
+int cu_count();
+
+// The kernel keeps one 256-row workgroup per CU, so G = cus * q + rem tiles cost q + 1 rounds however small rem is (one FHD
+// frame: 824 tiles at the 64-channel stage = 3.2 rounds, paid as 4). When the last partial round would fill at most half of
+// the CUs, its rows run as a second launch of the same kernel on 128-row tiles (8 waves, two workgroups per CU): about half
+// a round instead of a whole one. An output row's sum runs over the offsets in the same order whatever tile it sits in:
+// bitwise identical to the single launch (VX_CONV_NO_SPLIT_TAIL selects that one).
+template <int CIN, int COUT_PAD, int WAVES>
+int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
+  constexpr int R = 16 * WAVES;
+  const long long tiles = vx_cdiv(a.n_out, R);
+  const int cus = cu_count();
+  const long long rem = tiles % cus;
+  if (!a.no_split && a.cout <= COUT_PAD && rem > 0 && 2 * rem <= cus && tiles > rem) {
+    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles - rem, stream)) return rc;
+    const long long base = (tiles - rem) * R;
+    return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2>(a, base, vx_cdiv(a.n_out - base, R / 2), stream);
+  }
+  return launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles, stream);
 }
 
 template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1>
