@@ -88,6 +88,24 @@ int32_t vx_voxelize_hard_batch(const float* d_points, int32_t n_frames, const in
                                int64_t* d_num_voxels, int64_t* h_num_voxels, void* d_workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Allocation-free form of vx_voxelize_hard. It has NO counterpart in the reference: it exists for callers
+ * that cannot allocate device memory or carry a workspace -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. Same arguments and results as vx_voxelize_hard minus the workspace pair: the
+ * scratch (hash table, per-point and per-voxel index arrays, scan partials) is a 16 MiB file-scope __device__
+ * array of the library, one copy per GPU held until the process ends, whose device address is looked up once
+ * per device (vx_voxelize_static_init, or the first call on that device).
+ * Limit: n_points <= vx_voxelize_static_max_points() (262144); larger clouds return VX_ERR_CAPACITY.
+ * The call allocates nothing (no hipMalloc / hipFree / allocating library routine); pass h_num_voxels = NULL to
+ * keep it free of host copies and synchronisation as well. Every call on one GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+int64_t vx_voxelize_static_max_points(void);
+int32_t vx_voxelize_static_init(void);
+int32_t vx_voxelize_hard_static(const float* d_points, int64_t n_points, int32_t n_feat,
+                                const float* voxel_size, const float* range, int32_t max_points,
+                                int64_t max_voxels, int32_t batch_idx, int32_t* d_coords,
+                                int32_t* d_num_points, float* d_voxels, float* d_mean, int64_t cap,
+                                int64_t* d_num_voxels, int64_t* h_num_voxels, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Rulebooks (indice pairs). Stored output-major: nbr[k][o] = input row feeding output row o
  * through kernel offset k = (kz*KH + ky)*KW + kx, or -1. Row stride of nbr is nbr_ld (>= n_out).

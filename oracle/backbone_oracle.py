@@ -110,8 +110,10 @@ def sp_middle_resnet_fhd(voxel_features, coors, batch_size, input_shape, sd, tra
     return d.reshape(n, c * dd, h, w), t
 
 
-def multi_view_backbone(voxel_features, coors, batch_size, input_shape, sd, train=False, stats=None):
-    """multiview.py:88-106. returns (bev f32[B,C*D,H,W], rv f32[B,C*W,H,D])."""
+def multi_view_backbone(voxel_features, coors, batch_size, input_shape, sd, train=False, stats=None,
+                        return_tensors=False):
+    """multiview.py:88-106. returns (bev f32[B,C*D,H,W], rv f32[B,C*W,H,D]) (+ the two sparse tensors they were
+    densified from when return_tensors is set: tests compare active sets with them)."""
     sparse_shape = (np.array(input_shape[::-1]) + [1, 0, 0]).tolist()
     t = Tensor(np.asarray(voxel_features, np.float32), np.asarray(coors, np.int32), sparse_shape, batch_size)
     t = run_sequential(t, sd, "middle_conv", _middle(False), train, stats)
@@ -123,4 +125,16 @@ def multi_view_backbone(voxel_features, coors, batch_size, input_shape, sd, trai
     rv = so.to_dense(tr.feat, tr.coords, batch_size, tr.shape)
     n, c, d, h, w = rv.shape
     rv = np.ascontiguousarray(rv.transpose(0, 1, 4, 3, 2)).reshape(n, c * w, h, d)
+    if return_tensors:
+        return bev, rv, tb, tr
     return bev, rv
+
+
+def active_mask(t, layout="bev"):
+    """bool array shaped like the densified output of sparse tensor `t`: True on every element of an active site."""
+    ones = np.ones((t.feat.shape[0], t.feat.shape[1]), dtype=np.float32)
+    d = so.to_dense(ones, t.coords, t.batch, t.shape)
+    n, c, dd, h, w = d.shape
+    if layout == "bev":
+        return d.reshape(n, c * dd, h, w) != 0
+    return np.ascontiguousarray(d.transpose(0, 1, 4, 3, 2)).reshape(n, c * w, h, dd) != 0

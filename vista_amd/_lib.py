@@ -29,6 +29,11 @@ SIGNATURES = {
     "vx_voxelize_hard_batch": (c_int32, [c_void_p, c_int32, c_i64p, c_int32, c_f32p, c_f32p, c_int32, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_i64p,
                                          c_void_p, c_size_t, c_void_p]),
+    "vx_voxelize_static_max_points": (c_int64, []),
+    "vx_voxelize_static_init": (c_int32, []),
+    "vx_voxelize_hard_static": (c_int32, [c_void_p, c_int64, c_int32, c_f32p, c_f32p, c_int32, c_int64, c_int32,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_i64p,
+                                          c_void_p]),
     "vx_rulebook_workspace_bytes": (c_size_t, [c_int64, c_int32, c_i32p]),
     "vx_rulebook_subm": (c_int32, [c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_void_p, c_int64,
                                    c_void_p, c_size_t, c_void_p]),

@@ -17,6 +17,8 @@
 // (point_cloud_ops.py:173-174); this file is compiled with -ffp-contract=off and no fast-math.
 #include <math.h>
 
+#include <mutex>
+
 #include "vx_common.h"
 
 namespace {
@@ -353,4 +355,74 @@ extern "C" int32_t vx_voxelize_hard_batch(const float* d_points, int32_t n_frame
   return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, (int64_t)1 << 40, 0, n_frames,
                        frame_offsets, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
                        h_num_voxels, d_ws, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Allocation-free form (no counterpart in the reference; include/vx_abi.h). The workspace of voxelize_impl
+// -- hash table, slot / flag / rank / count / CSR arrays, scan partials -- lives in a file-scope device array
+// instead of a caller buffer. Its NAME is a host-side stand-in, not a device address: the address each GPU gave
+// its own copy is read once per device with hipGetSymbolAddress and only that pointer is ever handed to kernels,
+// memsets and copies.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int64_t kStaticMaxPoints = 262144;   // one 10-sweep nuScenes-shaped frame is ~247 k points
+// carve(kStaticMaxPoints): 8 MiB table (2^19 slots x 16 B) + 7 int32 arrays of 1 MiB + 64 B total + scan partials (< 2 KiB)
+constexpr size_t kStaticBytes = (size_t)16 << 20;
+__device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[64];                        // per device: device address of that GPU's copy of `scratch`
+
+int32_t scratch_address(void** out) {
+  int dev = -1;
+  VX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) {
+    vx_set_error("voxelize_static: device index %d out of range", dev);
+    return VX_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    VX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));   // with device `dev` current: ITS copy of the array
+    if (!p) {
+      vx_set_error("voxelize_static: hipGetSymbolAddress returned a null address");
+      return VX_ERR_HIP;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return VX_OK;
+}
+}  // namespace
+
+extern "C" int64_t vx_voxelize_static_max_points(void) { return kStaticMaxPoints; }
+
+extern "C" int32_t vx_voxelize_static_init(void) {
+  void* p = nullptr;
+  return scratch_address(&p);
+}
+
+extern "C" int32_t vx_voxelize_hard_static(const float* d_points, int64_t n, int32_t nf,
+                                           const float* voxel_size, const float* range,
+                                           int32_t max_points, int64_t max_voxels, int32_t batch_idx,
+                                           int32_t* d_coords, int32_t* d_num_points, float* d_voxels,
+                                           float* d_mean, int64_t cap, int64_t* d_num_voxels,
+                                           int64_t* h_num_voxels, void* stream) {
+  if (n > kStaticMaxPoints) {
+    vx_set_error("voxelize_static: %lld points exceed the static scratch limit of %lld; use vx_voxelize_hard "
+                 "with a caller workspace", (long long)n, (long long)kStaticMaxPoints);
+    return VX_ERR_CAPACITY;
+  }
+  static_assert(kStaticBytes % 256 == 0, "scratch size");
+  if (carve(nullptr, n).bytes > kStaticBytes) {   // cannot happen for n <= kStaticMaxPoints; kept as a guard
+    vx_set_error("voxelize_static: workspace of %lld points does not fit the static scratch", (long long)n);
+    return VX_ERR_CAPACITY;
+  }
+  void* ws = nullptr;
+  if (int32_t rc = scratch_address(&ws)) return rc;
+  // voxelize_impl re-initialises everything it reads (table, counters) on every call, so the contents the last
+  // call left behind do not matter; it launches kernels, memsets and (only when h_num_voxels != NULL) one D2H copy.
+  return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, max_voxels, batch_idx, 1, nullptr,
+                       d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels, h_num_voxels, ws,
+                       kStaticBytes, stream);
 }

@@ -108,10 +108,11 @@ def _run(steps, st, geom_only=False):
 class FusedBackbone:
     """Eval-mode forward of SpMiddleResNetFHD / MultiViewBackbone with fused epilogues."""
 
-    def __init__(self, module, dtype=torch.float32):
+    def __init__(self, module, dtype=torch.float32, eager=True):
         dev = next(module.parameters()).device
         self.kind = type(module).__name__
         self.dtype = dtype
+        self.eager = bool(eager)
         self.mode = getattr(module, "mode", "bev")
         self.middle = _compile_sequential(module.middle_conv, dev, dtype)
         if self.kind == "MultiViewBackbone":
@@ -119,6 +120,13 @@ class FusedBackbone:
             self.rv = _compile_sequential(module.rv_conv, dev, dtype)
         elif self.kind != "SpMiddleResNetFHD":
             raise TypeError(f"unsupported backbone {self.kind}")
+
+    def dispatch_name(self):
+        return "eager per-layer launches"
+
+    def eager_twin(self):
+        """The same plan with per-layer launches from the host (each C-ABI call can then be bracketed by events)."""
+        return self
 
     @torch.no_grad()
     def __call__(self, voxel_features, coors, batch_size, input_shape, out=None):

@@ -167,6 +167,7 @@ class Rulebook:
         self.out_indices = out_indices
         self.kvol = ksize[0] * ksize[1] * ksize[2]
         self._pairs = None
+        self._num_pairs = None
         self.out_rank = None  # rank table of the output site set (strided convs): see rulebook_subm
         self._sorted = None
 
@@ -175,6 +176,12 @@ class Rulebook:
         if self._pairs is None:
             self._pairs = nbr_to_pairs(self.nbr)
         return self._pairs
+
+    def num_pairs(self):
+        """Active (input, output, offset) triples of this rulebook (one host sync, cached)."""
+        if self._num_pairs is None:
+            self._num_pairs = int((self.nbr[:, :self.n_out] >= 0).sum().item()) if self.n_out else 0
+        return self._num_pairs
 
     def sorted_table(self):
         """(nbr_sorted int32[K,n_out], perm int32[n_out]): mask-sorted row order for conv_fwd."""
@@ -222,19 +229,20 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize, rank=None):
     nbr = torch.empty((kvol, n), dtype=torch.int32, device=indices.device)
     lib = L.lib()
     if rank is not None:
-        with torch.cuda.device(indices.device), _Timed("rulebook_subm", n=n, kvol=kvol, nbr=nbr):
+        rb = Rulebook(nbr, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, spatial_shape, spatial_shape, indices)
+        with torch.cuda.device(indices.device), _Timed("rulebook_subm", n=n, kvol=kvol, rb=rb):
             rc = lib.vx_rulebook_subm_ranked(_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape),
                                              L.i32x3(ks), _ptr(rank), _ptr(nbr), max(n, 1), _stream())
         L.check(rc, "vx_rulebook_subm_ranked")
-        return Rulebook(nbr, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, spatial_shape, spatial_shape,
-                        indices)
+        return rb
     wsb = lib.vx_rulebook_workspace_bytes(n, int(batch_size), None)
     ws = _ws(wsb, indices.device)
-    with torch.cuda.device(indices.device), _Timed("rulebook_subm", n=n, kvol=kvol, nbr=nbr):
+    rb = Rulebook(nbr, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, spatial_shape, spatial_shape, indices)
+    with torch.cuda.device(indices.device), _Timed("rulebook_subm", n=n, kvol=kvol, rb=rb):
         rc = lib.vx_rulebook_subm(_ptr(indices), n, int(batch_size), L.i32x3(spatial_shape), L.i32x3(ks),
                                   _ptr(nbr), max(n, 1), _ptr(ws), wsb, _stream())
     L.check(rc, "vx_rulebook_subm")
-    return Rulebook(nbr, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, spatial_shape, spatial_shape, indices)
+    return rb
 
 
 def conv_out_shape(in_shape, ksize, stride, padding):
@@ -271,10 +279,10 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, tr
         rc = lib.vx_rulebook_conv_emit(*args, n_out, _ptr(out_idx), _ptr(nbr), max(n_out, 1), _ptr(nbr_t),
                                        max(n, 1), _ptr(rank), _ptr(ws), wsb, _stream())
         L.check(rc, "vx_rulebook_conv_emit")
-        if rec is not None:
-            rec["nbr"], rec["n_out"] = nbr, n_out
     rb = Rulebook(nbr, n, n_out, ks, st, pd, False, spatial_shape, list(osh), out_idx, nbr_t)
     rb.out_rank = rank if n and n_out else None
+    if rec is not None:
+        rec["rb"] = rb
     return rb
 
 
