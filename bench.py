@@ -56,6 +56,8 @@ def parse(argv=None):
                     help="--mode train: stock torch BatchNorm1d/ReLU/add kernels instead of the fused libvx ones (A/B)")
     ap.add_argument("--eager", action="store_true",
                     help="inference: per-layer launches from the host (no captured plan), the round-1 path (A/B)")
+    ap.add_argument("--dispatch", default=None, choices=["queued", "graph"],
+                    help="how a sync-free step is issued: launches queued on the stream, or one captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     a = ap.parse_args(argv)
@@ -325,7 +327,7 @@ def build_infer(a, dev, rank, dtype_name=None, geometry=None, batch=None):
     dtype = torch.float32 if dtype_name == "fp32" else torch.bfloat16
     net = models.load_numpy_state_dict(getattr(models, a.backbone)(num_input_features=5),
                                        backbone_state_dict(a.backbone)).to(dev).eval()
-    engine = FusedBackbone(net, dtype=dtype, eager=a.eager)
+    engine = FusedBackbone(net, dtype=dtype, eager=a.eager, dispatch=a.dispatch)
     frames = make_frames(geometry, batch, rank, dev)
     return gen, grid, engine, frames
 
@@ -333,14 +335,12 @@ def build_infer(a, dev, rank, dtype_name=None, geometry=None, batch=None):
 def make_step(a, gen, grid, engine, frames, tail=None):
     import torch
     from vista_amd.engine import FramePipeline
-    from vista_amd.voxel import voxelize_batch
     pipe = FramePipeline(gen, engine, groups=a.streams) if a.streams > 1 else None
 
     def step():
         if pipe is not None:
             return pipe(frames, grid, join=False)
-        mean, coords, _ = voxelize_batch(gen, frames)
-        out = engine(mean, coords, len(frames), grid)
+        out = engine.forward_frames(gen, frames, grid)   # captured plan, or per-layer launches when engine.eager
         if tail is not None:
             with torch.no_grad():
                 out = tail(*out)

@@ -215,6 +215,54 @@ int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int3
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * "_dn" forms: the same operations with their data-dependent ROW COUNTS RESIDENT ON THE DEVICE, so that the whole
+ * per-frame pass (voxelization, every rulebook, every convolution, dense()) can be queued -- or captured in a HIP
+ * graph -- without one host synchronisation. They replace the per-layer host dispatch of
+ * det3d/models/backbones/scn.py:332-381 / multiview.py:88-106 (one Python call + spconv's own host-side pair
+ * counting per layer) the way SURVEY.md 8f row N2 asks. Each takes
+ *   d_n  / d_n_in / d_n_out   device int64: the row count, written by the producing call on the same stream
+ *   cap / cap_in / cap_out    host upper bound: grids, table strides and buffer sizes are sized for it
+ * Kernels use min(count, capacity) rows and workgroups beyond the count exit at once; tile mapping, tail splitting
+ * and every row's summation order are the same functions of the count as in the host-count forms, so results are
+ * bitwise identical to them. A count above its capacity drops the surplus rows (never an out-of-bounds access):
+ * the caller reads the counts back after the pass, compares them with the capacities and re-runs with larger ones.
+ *
+ * vx_voxelize_hard_batch_dn   d_frame_offsets = DEVICE int64[n_frames + 1] (point ranges, [0] == 0); the point
+ *                             count is d_frame_offsets[n_frames] <= cap_points; d_num_voxels int64[n_frames + 1] =
+ *                             {total (NOT clamped to cap), per frame}; no max_voxels truncation (caller guarantees
+ *                             every frame has <= max_voxels points, as for vx_voxelize_hard_batch). Workspace:
+ *                             vx_voxelize_workspace_bytes(cap_points).
+ * vx_rulebook_subm_dn         workspace vx_rulebook_workspace_bytes(cap, batch, NULL)
+ * vx_rulebook_conv_dn         count + emit in one call: d_n_out receives the number of output sites (not clamped),
+ *                             d_out_coords / d_nbr (stride nbr_ld >= cap_out) / d_rank as vx_rulebook_conv_emit;
+ *                             *d_err (device int64, zeroed once by the caller) is set to 1 when a coordinate lies
+ *                             outside batch x in_shape. Workspace vx_rulebook_workspace_bytes(cap_in, batch, out_shape).
+ * vx_rulebook_subm_ranked_dn, vx_spconv_fwd_dn, vx_to_dense_dn   as their host-count forms.
+ * ------------------------------------------------------------------------------------------- */
+int32_t vx_voxelize_hard_batch_dn(const float* d_points, int32_t n_frames, const int64_t* d_frame_offsets,
+                                  int64_t cap_points, int32_t n_feat, const float* voxel_size,
+                                  const float* range, int32_t max_points, int32_t* d_coords,
+                                  int32_t* d_num_points, float* d_mean, int64_t cap, int64_t* d_num_voxels,
+                                  void* d_workspace, size_t workspace_bytes, void* stream);
+int32_t vx_rulebook_subm_dn(const int32_t* d_coords, const int64_t* d_n, int64_t cap, int32_t batch,
+                            const int32_t* shape, const int32_t* ksize, int32_t* d_nbr, int64_t nbr_ld,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+int32_t vx_rulebook_conv_dn(const int32_t* d_coords, const int64_t* d_n_in, int64_t cap_in, int32_t batch,
+                            const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
+                            const int32_t* pad, int32_t* out_shape, int64_t cap_out, int32_t* d_out_coords,
+                            int64_t* d_n_out, int32_t* d_nbr, int64_t nbr_ld, void* d_rank, int64_t* d_err,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+int32_t vx_rulebook_subm_ranked_dn(const int32_t* d_coords, const int64_t* d_n, int64_t cap, int32_t batch,
+                                   const int32_t* shape, const int32_t* ksize, const void* d_rank,
+                                   int32_t* d_nbr, int64_t nbr_ld, void* stream);
+int32_t vx_spconv_fwd_dn(const void* d_in, int64_t cap_in, int32_t cin, const void* d_weight, int32_t kvol,
+                         int32_t cout, const int32_t* d_nbr, int64_t nbr_ld, const int64_t* d_n_out,
+                         int64_t cap_out, const float* d_bias, const float* d_scale, const float* d_shift,
+                         const void* d_residual, int32_t flags, void* d_out, int32_t dtype, void* stream);
+int32_t vx_to_dense_dn(const void* d_feat, const int32_t* d_coords, const int64_t* d_n, int64_t cap, int32_t c,
+                       int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Train-mode BatchNorm1d over sparse features [n][c] (fp32, c a power of two in [8, 512]), fused with the
  * residual add and ReLU that follow it. Replaces the torch BatchNorm1d / add / ReLU passes over `.features`
  * of det3d/models/backbones/scn.py:82-98 (block) and :333-364 (conv + BN + ReLU) in the training step

@@ -62,6 +62,21 @@ SIGNATURES = {
                                   c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "vx_to_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
                               c_int32, c_void_p]),
+    "vx_voxelize_hard_batch_dn": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_f32p, c_f32p, c_int32,
+                                            c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
+                                            c_void_p]),
+    "vx_rulebook_subm_dn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_void_p, c_int64,
+                                      c_void_p, c_size_t, c_void_p]),
+    "vx_rulebook_conv_dn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p,
+                                      c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "vx_rulebook_subm_ranked_dn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_i32p, c_i32p, c_void_p,
+                                             c_void_p, c_int64, c_void_p]),
+    "vx_spconv_fwd_dn": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                   c_int32, c_void_p]),
+    "vx_to_dense_dn": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
+                                 c_int32, c_void_p]),
     "vx_bn_workspace_bytes": (c_size_t, [c_int32]),
     "vx_bn_stats": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vx_bn_finalize": (c_int32, [c_void_p, c_int32, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p,

@@ -10,6 +10,9 @@
 //   spconv_f32_generic any cin <= 128 / strided weights (first layer cin=5): simple, LDS staged
 // dgrad runs on the same kernels with the roles of in/out swapped and a transposed weight copy.
 #include <atomic>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "vx_common.h"
 
@@ -39,7 +42,22 @@ struct ConvArgs {
   const int* perm;      // optional: tile row j computes output row perm[j] (table is pre-permuted)
   const void* zero;     // 512 zero bytes in device memory: what a missing neighbour reads
   int no_split;         // launch spconv_w8's plain grid (VX_CONV_NO_SPLIT_TAIL)
+  // "_dn" entry points (row count resident on the device, e.g. under HIP graph capture): when non-null the kernels
+  // take min(*n_out_dev, n_out) as the row count, n_out is only the capacity the grid was sized for, and surplus
+  // workgroups exit at once. Tile -> row mapping, split tails and every output row's summation order are the same
+  // functions of the row count as on the host, so results are bitwise those of the host-count launch.
+  const long long* n_out_dev;
+  int cus;              // compute units of the device (tail-splitting decisions taken on the device)
 };
+
+__device__ __forceinline__ long long rows_of(const ConvArgs& a) {
+  long long n = a.n_out;
+  if (a.n_out_dev) {
+    const long long d = *a.n_out_dev;
+    n = d < n ? (d > 0 ? d : 0) : n;
+  }
+  return n;
+}
 
 // bijective XCD-aware remap: consecutive tiles (which share gathered neighbours) run on one XCD
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
@@ -60,7 +78,10 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const long long tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long long n_out = rows_of(a);
+  const long long ntiles = (n_out + kTileRows - 1) / kTileRows;
+  if ((long long)blockIdx.x >= ntiles) return;
+  const long long tile = xcd_remap(blockIdx.x, (unsigned)ntiles);
   const long long row0 = tile * kTileRows + wave * 32;
   const int col0 = blockIdx.y * COUT_PAD;
   const bool vec_in = (a.cin & 3) == 0;
@@ -75,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
   for (int k = 0; k < a.kvol; ++k) {
     const int krow = a.flip_k ? a.kvol - 1 - k : k;
     int myrow = -1;
-    if (lane < 32 && row0 + lane < a.n_out) myrow = a.nbr[(long long)krow * a.ld + row0 + lane];
+    if (lane < 32 && row0 + lane < n_out) myrow = a.nbr[(long long)krow * a.ld + row0 + lane];
     const bool wave_any = __ballot(myrow >= 0) != 0ull;
     // also the WAR barrier protecting the LDS images of the previous offset
     if (!__syncthreads_or(wave_any ? 1 : 0)) continue;
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= a.n_out) continue;
+      if (row >= n_out) continue;
       const long long orow = a.perm ? a.perm[row] : row;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
@@ -247,7 +268,7 @@ extern "C" int32_t vx_debug_read(unsigned long long* h8) {
 
 // Body of the LDS-staged row-stationary kernel for row tile `tile` and output columns [col0, col0 + COUT_PAD).
 template <typename T, int CIN, int COUT_PAD>
-__device__ __forceinline__ void w8_body(const ConvArgs& a, const long long tile, const int col0) {
+__device__ __forceinline__ void w8_body(const ConvArgs& a, const long long n_out, const long long tile, const int col0) {
   constexpr int VPQ = Elem<T>::VPQ;
   constexpr int CK = kRowBytes / (int)sizeof(T);      // staged values per chunk (64 / 128)
   constexpr int QPR = kRowBytes / 16;                 // 16-byte pieces per staged row (16)
@@ -276,7 +297,7 @@ __device__ __forceinline__ void w8_body(const ConvArgs& a, const long long tile,
   for (int i = 0; i < kKSlots / 2; ++i) {
     const int ks = 2 * i + h;
     int idx = -1;
-    if (ks < a.kvol && row0 + r < a.n_out) {
+    if (ks < a.kvol && row0 + r < n_out) {
       const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
       idx = a.nbr[(long long)krow * a.ld + row0 + r];
     }
@@ -422,7 +443,7 @@ __device__ __forceinline__ void w8_body(const ConvArgs& a, const long long tile,
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= a.n_out) continue;
+      if (row >= n_out) continue;
       const long long orow = a.perm ? a.perm[row] : row;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
@@ -435,7 +456,10 @@ __device__ __forceinline__ void w8_body(const ConvArgs& a, const long long tile,
 
 template <typename T, int CIN, int COUT_PAD>
 __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
-  w8_body<T, CIN, COUT_PAD>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y * COUT_PAD);
+  const long long n_out = rows_of(a);
+  const long long ntiles = (n_out + kW8Rows - 1) / kW8Rows;
+  if ((long long)blockIdx.x >= ntiles) return;
+  w8_body<T, CIN, COUT_PAD>(a, n_out, xcd_remap(blockIdx.x, (unsigned)ntiles), blockIdx.y * COUT_PAD);
 }
 
 // Split-tail launch. The kernel keeps one workgroup per CU (its LDS holds two W chunks), so a grid of
@@ -445,12 +469,21 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8(ConvArgs a) {
 // (2*rem <= 256 workgroups -> one round of roughly half the duration). Only used for cout == COUT_PAD.
 template <typename T, int CIN, int COUT_PAD>
 __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8_split_tail(ConvArgs a, int n_full) {
+  const long long n_out = rows_of(a);
+  int n_half = (int)gridDim.x - n_full;          // half-width workgroups (two per tail tile)
+  if (a.n_out_dev) {                             // the host's split rule (launch_w8), from the device row count
+    const long long tiles = (n_out + kW8Rows - 1) / kW8Rows, rem = tiles % a.cus;
+    const bool split = rem > 0 && 2 * rem <= a.cus;
+    n_full = (int)(split ? tiles - rem : tiles);
+    n_half = split ? (int)(2 * rem) : 0;
+  }
   const int b = blockIdx.x;
   if (b < n_full) {
-    w8_body<T, CIN, COUT_PAD>(a, xcd_remap(b, n_full), 0);
+    w8_body<T, CIN, COUT_PAD>(a, n_out, xcd_remap(b, n_full), 0);
   } else {
     const int j = b - n_full;
-    w8_body<T, CIN, COUT_PAD / 2>(a, n_full + (j >> 1), (j & 1) * (COUT_PAD / 2));
+    if (j >= n_half) return;
+    w8_body<T, CIN, COUT_PAD / 2>(a, n_out, n_full + (j >> 1), (j & 1) * (COUT_PAD / 2));
   }
 }
 
@@ -478,7 +511,10 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
   const T* zero = reinterpret_cast<const T*>(a.zero);
 
   const int r = lane & 31, h = lane >> 5;
-  const long long tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long long n_out = rows_of(a);
+  const long long ntiles = (n_out + kW8Rows - 1) / kW8Rows;
+  if ((long long)blockIdx.x >= ntiles) return;
+  const long long tile = xcd_remap(blockIdx.x, (unsigned)ntiles);
   const long long row0 = tile * kW8Rows + wave * 32;
   const int col0 = blockIdx.y * COUT_PAD;
   const int nchunks = (a.kvol * CIN + CK - 1) / CK;
@@ -488,7 +524,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
   for (int i = 0; i < kKSlots / 2; ++i) {
     const int ks = 2 * i + h;
     int idx = -1;
-    if (ks < a.kvol && row0 + r < a.n_out) {
+    if (ks < a.kvol && row0 + r < n_out) {
       const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
       idx = a.nbr[(long long)krow * a.ld + row0 + r];
     }
@@ -606,7 +642,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= a.n_out) continue;
+      if (row >= n_out) continue;
       const long long orow = a.perm ? a.perm[row] : row;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
@@ -669,7 +705,10 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int grp = wave / NS, t0 = (wave % NS) * NT;  // this wave's pair group and first channel tile
-  const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
+  const long long n_out = rows_of(a);
+  const long long ntiles = (n_out + kCbRows - 1) / kCbRows;
+  if ((long long)blockIdx.x >= ntiles) return;
+  const long long row0 = (long long)xcd_remap(blockIdx.x, (unsigned)ntiles) * kCbRows;
   const int col0 = blockIdx.y * COUT_PAD;
   const char* in = reinterpret_cast<const char*>(a.in);
   const char* wgt = reinterpret_cast<const char*>(a.w);
@@ -686,7 +725,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
       const int* t = a.nbr + (long long)krow * a.ld + row0;
 #pragma unroll
       for (int j = 0; j < NE; ++j)
-        if (row0 + lane + 64 * j < a.n_out) e[j] = t[lane + 64 * j];
+        if (row0 + lane + 64 * j < n_out) e[j] = t[lane + 64 * j];
     }
   };
   // compaction of the tile's entries; this wave keeps pairs [32*grp, 32*grp + 32):
@@ -816,7 +855,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
   for (int e = threadIdx.x; e < kCbRows * CQ; e += kCbThreads) {
     const int rr = e / CQ, c = col0 + 4 * (e % CQ);
     const long long row = row0 + rr;
-    if (row >= a.n_out) continue;
+    if (row >= n_out) continue;
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(sAcc + rr * ACC_LD + 4 * (e % CQ));
     const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -854,7 +893,7 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 #define VX_CB16 1
 #endif
 template <int CIN, int COUT_PAD, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long row_base) {
+__global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long row_base, long long ntiles, int part) {
   constexpr int kCbRows = 16 * WAVES, kCbThreads = 64 * WAVES;
   static_assert(kCbRows % 64 == 0 && COUT_PAD % 16 == 0 && CIN % 16 == 0, "tile shape");
   constexpr int NE = kCbRows / 64;                   // neighbour entries per producer lane
@@ -875,7 +914,22 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, kq = lane >> 4;
   const bool producer = wave == WAVES - 1;
-  const long long row0 = row_base + (long long)xcd_remap(blockIdx.x, gridDim.x) * kCbRows;
+  const long long n_out = rows_of(a);
+  if (a.n_out_dev) {      // launch_cb16's split between full-height tiles (part 0) and a half-height tail (part 1)
+    const int rf = part ? 2 * kCbRows : kCbRows;
+    const long long tiles = (n_out + rf - 1) / rf, rem = tiles % a.cus;
+    const bool split = !a.no_split && a.cout <= COUT_PAD && rem > 0 && 2 * rem <= a.cus && tiles > rem;
+    if (part == 0) {
+      row_base = 0;
+      ntiles = split ? tiles - rem : tiles;
+    } else {
+      if (!split) return;
+      row_base = (tiles - rem) * rf;
+      ntiles = (n_out - row_base + kCbRows - 1) / kCbRows;
+    }
+  }
+  if ((long long)blockIdx.x >= ntiles) return;
+  const long long row0 = row_base + (long long)xcd_remap(blockIdx.x, (unsigned)ntiles) * kCbRows;
   const int col0 = blockIdx.y * COUT_PAD;
   const char* in = reinterpret_cast<const char*>(a.in);
   const char* wgt = reinterpret_cast<const char*>(a.w);
@@ -892,7 +946,7 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
       const int* t = a.nbr + (long long)krow * a.ld + row0;
 #pragma unroll
       for (int j = 0; j < NE; ++j)
-        if (row0 + lane + 64 * j < a.n_out) e[j] = t[lane + 64 * j];
+        if (row0 + lane + 64 * j < n_out) e[j] = t[lane + 64 * j];
     }
   };
   auto publish = [&](const int (&e)[NE], int lb) {
@@ -1041,7 +1095,7 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
   for (int e = threadIdx.x; e < kCbRows * CQ; e += kCbThreads) {
     const int rr = e / CQ, c = col0 + 4 * (e % CQ);
     const long long row = row0 + rr;
-    if (row >= a.n_out) continue;
+    if (row >= n_out) continue;
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(sAcc + rr * ACC_LD + 4 * (e % CQ));
     const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -1057,22 +1111,36 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
   }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): keeps repeated launches -- and launches
+// recorded under stream capture -- free of the attribute call.
+int32_t set_lds_once(const void* kern, size_t lds) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  VX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kern, dev})) return VX_OK;
+  VX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  done.insert({kern, dev});
+  return VX_OK;
+}
+
+int cu_count();
+
 template <int CIN, int COUT_PAD, int WAVES>
-int32_t launch_cb16_rows(const ConvArgs& a, long long row_base, long long n_tiles, hipStream_t stream) {
+int32_t launch_cb16_rows(const ConvArgs& a, long long row_base, long long n_tiles, int part, hipStream_t stream) {
   constexpr int R = 16 * WAVES;
   constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * 4 + 16) +
                          (size_t)2 * R * sizeof(int2) + 16;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert(((R + 1) * (COUT_PAD + 4) * 4) % 16 == 0 && (2 * COUT_PAD * (CIN * 4 + 16)) % 8 == 0, "LDS alignment");
   auto kern = spconv_cb16<CIN, COUT_PAD, WAVES>;
-  VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
   dim3 grid((unsigned)n_tiles, (unsigned)vx_cdiv(a.cout, COUT_PAD));
-  kern<<<grid, 64 * WAVES, lds, stream>>>(a, row_base);
+  kern<<<grid, 64 * WAVES, lds, stream>>>(a, row_base, n_tiles, part);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }
-
-int cu_count();
 
 // The kernel keeps one 256-row workgroup per CU, so G = cus * q + rem tiles cost q + 1 rounds however small rem is (one FHD
 // frame: 824 tiles at the 64-channel stage = 3.2 rounds, paid as 4). When the last partial round would fill at most half of
@@ -1083,14 +1151,23 @@ template <int CIN, int COUT_PAD, int WAVES>
 int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
   constexpr int R = 16 * WAVES;
   const long long tiles = vx_cdiv(a.n_out, R);
-  const int cus = cu_count();
+  const int cus = a.cus;
+  if (a.n_out_dev) {
+    // row count on the device: a.n_out is the capacity. Part 0 over every tile the capacity allows, part 1 (the
+    // half-height tail, at most `cus` tiles) whenever the split rule could apply; the kernels take the same
+    // decisions as below from the device count and surplus workgroups exit.
+    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles, 0, stream)) return rc;
+    if (!a.no_split && a.cout <= COUT_PAD)
+      return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2>(a, 0, cus, 1, stream);
+    return VX_OK;
+  }
   const long long rem = tiles % cus;
   if (!a.no_split && a.cout <= COUT_PAD && rem > 0 && 2 * rem <= cus && tiles > rem) {
-    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles - rem, stream)) return rc;
+    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles - rem, 0, stream)) return rc;
     const long long base = (tiles - rem) * R;
-    return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2>(a, base, vx_cdiv(a.n_out - base, R / 2), stream);
+    return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2>(a, base, vx_cdiv(a.n_out - base, R / 2), 1, stream);
   }
-  return launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles, stream);
+  return launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles, 0, stream);
 }
 
 template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1>
@@ -1099,7 +1176,7 @@ int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
   constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * sizeof(T) + 16);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = spconv_cb<T, CIN, COUT_PAD, WAVES, NS>;
-  VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
   dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   kern<<<grid, 64 * WAVES, lds, stream>>>(a);
   VX_LAUNCH_CHECK();
@@ -1168,17 +1245,20 @@ int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   constexpr size_t lds = kLdsGather ? lds_l : lds_d;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = kLdsGather ? spconv_w8<T, CIN, COUT_PAD> : spconv_w8d<T, CIN, COUT_PAD>;
-  VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds));
+  if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
   dim3 grid((unsigned)vx_cdiv(a.n_out, kW8Rows), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   if constexpr (kLdsGather && COUT_PAD >= 64) {
     const long long tiles = grid.x;
-    const int cus = cu_count();
+    const int cus = a.cus;
     const long long rem = tiles % cus;
-    if (VX_W8_SPLIT_TAIL && !a.no_split && a.cout == COUT_PAD && rem > 0 && 2 * rem <= cus) {
+    const bool may_split = VX_W8_SPLIT_TAIL && !a.no_split && a.cout == COUT_PAD;
+    // device row count: the kernel applies the split rule itself; room for the largest tail (cus / 2 tiles, two
+    // half-width workgroups each) beside the capacity's tiles
+    if (may_split && (a.n_out_dev || (rem > 0 && 2 * rem <= cus))) {
       auto kt = spconv_w8_split_tail<T, CIN, COUT_PAD>;
-      VX_HIP(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      kt<<<dim3((unsigned)(tiles + rem)), kW8Threads, lds, stream>>>(a, (int)(tiles - rem));
+      if (int32_t rc = set_lds_once((const void*)kt, lds)) return rc;
+      const long long g = a.n_out_dev ? tiles + cus : tiles + rem;
+      kt<<<dim3((unsigned)g), kW8Threads, lds, stream>>>(a, (int)(tiles - rem));
       VX_LAUNCH_CHECK();
       return VX_OK;
     }
@@ -1224,7 +1304,10 @@ __global__ __launch_bounds__(64) void spconv_f32_ws(ConvArgs a, const f32x4* __r
   __shared__ int sIdx[kKSlots * 32];
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
-  const long long row0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * 32;
+  const long long n_out = rows_of(a);
+  const long long ntiles = (n_out + 31) / 32;
+  if ((long long)blockIdx.x >= ntiles) return;
+  const long long row0 = (long long)xcd_remap(blockIdx.x, (unsigned)ntiles) * 32;
   const int nchunks = (a.kvol * CIN + CK - 1) / CK;
   const float* in = a.in;
 
@@ -1233,7 +1316,7 @@ __global__ __launch_bounds__(64) void spconv_f32_ws(ConvArgs a, const f32x4* __r
   for (int i = 0; i < kKSlots / 2; ++i) {
     const int ks = 2 * i + h;
     int idx = -1;
-    if (ks < a.kvol && row0 + r < a.n_out) {
+    if (ks < a.kvol && row0 + r < n_out) {
       const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
       idx = a.nbr[(long long)krow * a.ld + row0 + r];
     }
@@ -1317,7 +1400,7 @@ __global__ __launch_bounds__(64) void spconv_f32_ws(ConvArgs a, const f32x4* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= a.n_out) continue;
+      if (row >= n_out) continue;
       const long long orow = a.perm ? a.perm[row] : row;
       float v = acc[t][i] + b;
       if (a.scale || a.shift) v = v * sc + sh;
@@ -1382,8 +1465,7 @@ int32_t launch(const ConvArgs& a, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = spconv_f32_generic<CIN_PAD, COUT_PAD>;
   if (lds > 64 * 1024)
-    VX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+    if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
   dim3 grid((unsigned)vx_cdiv(a.n_out, kTileRows), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   kern<<<grid, kThreads, lds, stream>>>(a);
   VX_LAUNCH_CHECK();
@@ -1437,12 +1519,12 @@ int32_t zero_row_address(const void** out) {
 }
 }  // namespace
 
-extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
-                                 int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
-                                 int64_t n_out, const float* d_bias, const float* d_scale,
-                                 const float* d_shift, const void* d_residual, int32_t flags,
-                                 const int32_t* d_perm, const void* d_wpack, void* d_out,
-                                 int32_t dtype, void* stream) {
+static int32_t spconv_fwd_impl(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
+                               int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
+                               int64_t n_out, const int64_t* d_n_out, const float* d_bias,
+                               const float* d_scale, const float* d_shift, const void* d_residual,
+                               int32_t flags, const int32_t* d_perm, const void* d_wpack, void* d_out,
+                               int32_t dtype, void* stream) {
   VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "spconv_fwd: dtype must be VX_F32 or VX_BF16");
   VX_REQUIRE(cin >= 1 && cin <= 128 && cout >= 1 && kvol >= 1 && kvol <= 125,
              "spconv_fwd: need 1 <= cin <= 128, cout >= 1, 1 <= kvol <= 125");
@@ -1472,6 +1554,8 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
   a.out = (float*)d_out;
   a.dtype = dtype;
   a.perm = d_perm;
+  a.n_out_dev = (const long long*)d_n_out;
+  a.cus = cu_count();
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
   if (!(flags & VX_CONV_NO_COMPACT)) {   // fp32, Cin in {16,32,64}, Cout <= 128: per-offset compaction kernel
     const int32_t rc = dispatch_cb(a, (hipStream_t)stream);
@@ -1483,6 +1567,26 @@ extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, co
     if (rc <= 0) return rc;
   }
   return dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t vx_spconv_fwd(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
+                                 int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
+                                 int64_t n_out, const float* d_bias, const float* d_scale,
+                                 const float* d_shift, const void* d_residual, int32_t flags,
+                                 const int32_t* d_perm, const void* d_wpack, void* d_out,
+                                 int32_t dtype, void* stream) {
+  return spconv_fwd_impl(d_in, n_in, cin, d_weight, kvol, cout, d_nbr, nbr_ld, n_out, nullptr, d_bias, d_scale,
+                         d_shift, d_residual, flags, d_perm, d_wpack, d_out, dtype, stream);
+}
+
+extern "C" int32_t vx_spconv_fwd_dn(const void* d_in, int64_t cap_in, int32_t cin, const void* d_weight,
+                                    int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
+                                    const int64_t* d_n_out, int64_t cap_out, const float* d_bias,
+                                    const float* d_scale, const float* d_shift, const void* d_residual,
+                                    int32_t flags, void* d_out, int32_t dtype, void* stream) {
+  VX_REQUIRE(d_n_out && cap_out >= 1, "spconv_fwd_dn: need the device row count and a capacity >= 1");
+  return spconv_fwd_impl(d_in, cap_in, cin, d_weight, kvol, cout, d_nbr, nbr_ld, cap_out, d_n_out, d_bias, d_scale,
+                         d_shift, d_residual, flags, nullptr, nullptr, d_out, dtype, stream);
 }
 
 extern "C" size_t vx_spconv_pack_weight_bytes(int32_t cin, int32_t cout, int32_t kvol) {
@@ -1531,6 +1635,8 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.out = (float*)d_din;
   a.dtype = dtype;
   a.perm = nullptr;
+  a.n_out_dev = nullptr;
+  a.cus = cu_count();
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
   {
     const int32_t rc = dispatch_cb(a, (hipStream_t)stream);

@@ -11,12 +11,18 @@ constexpr int kRows = 64;
 template <typename T>  // moved as raw 4- or 2-byte words (fp32 / bf16)
 __global__ __launch_bounds__(kThreads) void to_dense_kernel(const T* __restrict__ feat,
                                                             const int* __restrict__ coords,
-                                                            long long n, int c, int d, int hh, int ww,
+                                                            long long n, const long long* __restrict__ d_n,
+                                                            int c, int d, int hh, int ww,
                                                             T* __restrict__ dense) {
   extern __shared__ __attribute__((aligned(16))) char tile_raw[];
   T* tile = reinterpret_cast<T*>(tile_raw);  // [kRows][c + 1]
   const int cp = c + 1;
   const long long row0 = (long long)blockIdx.x * kRows;
+  if (d_n) {                                 // "_dn" form: n is the capacity, the row count stays on the device
+    const long long dn = *d_n;
+    n = dn < n ? (dn > 0 ? dn : 0) : n;
+  }
+  if (row0 >= n) return;
   const int rows = (int)((n - row0) < kRows ? (n - row0) : kRows);
   for (int idx = threadIdx.x; idx < rows * c; idx += kThreads) {
     const int rr = idx / c, cc = idx - rr * c;
@@ -33,10 +39,9 @@ __global__ __launch_bounds__(kThreads) void to_dense_kernel(const T* __restrict_
 }
 }  // namespace
 
-extern "C" int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int32_t c,
-                               int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
-                               void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int32_t to_dense_impl(const void* d_feat, const int32_t* d_coords, int64_t n, const int64_t* d_n,
+                             int32_t c, int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
+                             hipStream_t stream) {
   VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "to_dense: dtype must be VX_F32 or VX_BF16");
   const size_t esz = dtype == VX_F32 ? 4 : 2;
   VX_REQUIRE(shape && d_dense && batch >= 1 && c >= 1 && c <= 4096 && n >= 0, "to_dense: bad arguments");
@@ -48,10 +53,25 @@ extern "C" int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int6
   const unsigned grid = (unsigned)vx_cdiv(n, kRows);
   if (dtype == VX_F32)
     to_dense_kernel<uint32_t><<<grid, kThreads, lds, stream>>>(
-        (const uint32_t*)d_feat, d_coords, n, c, shape[0], shape[1], shape[2], (uint32_t*)d_dense);
+        (const uint32_t*)d_feat, d_coords, n, (const long long*)d_n, c, shape[0], shape[1], shape[2],
+        (uint32_t*)d_dense);
   else
     to_dense_kernel<uint16_t><<<grid, kThreads, lds, stream>>>(
-        (const uint16_t*)d_feat, d_coords, n, c, shape[0], shape[1], shape[2], (uint16_t*)d_dense);
+        (const uint16_t*)d_feat, d_coords, n, (const long long*)d_n, c, shape[0], shape[1], shape[2],
+        (uint16_t*)d_dense);
   VX_LAUNCH_CHECK();
   return VX_OK;
+}
+
+extern "C" int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int32_t c,
+                               int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
+                               void* stream) {
+  return to_dense_impl(d_feat, d_coords, n, nullptr, c, batch, shape, d_dense, dtype, (hipStream_t)stream);
+}
+
+extern "C" int32_t vx_to_dense_dn(const void* d_feat, const int32_t* d_coords, const int64_t* d_n, int64_t cap,
+                                  int32_t c, int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
+                                  void* stream) {
+  VX_REQUIRE(d_n && cap >= 1, "to_dense_dn: need the device row count and a capacity >= 1");
+  return to_dense_impl(d_feat, d_coords, cap, d_n, c, batch, shape, d_dense, dtype, (hipStream_t)stream);
 }

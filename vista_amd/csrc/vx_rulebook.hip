@@ -18,7 +18,25 @@ struct ConvGeom {
   int out_shape[3];
   int k[3], s[3], p[3];
   int kvol;
+  int batch;
 };
+
+// Row count of a launch: `n` from the host, or -- for the "_dn" entry points, whose counts stay on the device --
+// min(*d_n, n) with n the capacity the grid was sized for.
+__device__ __forceinline__ long long rows_of(long long n, const long long* d_n) {
+  if (d_n) {
+    const long long d = *d_n;
+    n = d < n ? (d > 0 ? d : 0) : n;
+  }
+  return n;
+}
+
+// (batch, z, y, x) inside the input grid? Rows that are not would index the occupancy / rank tables out of bounds:
+// they are skipped and reported through the error word (plain idempotent store of 1).
+__device__ __forceinline__ bool site_ok(const int4& c, const ConvGeom& g) {
+  return c.x >= 0 && c.x < g.batch && c.y >= 0 && c.y < g.in_shape[0] && c.z >= 0 && c.z < g.in_shape[1] &&
+         c.w >= 0 && c.w < g.in_shape[2];
+}
 
 __device__ __forceinline__ long long lin_idx(int b, int z, int y, int x, const int* sh) {
   return (((long long)b * sh[0] + z) * sh[1] + y) * sh[2] + x;
@@ -30,10 +48,12 @@ __global__ __launch_bounds__(kThreads) void hash_clear(VxSlot* t, long long cap)
 }
 
 __global__ __launch_bounds__(kThreads) void hash_build(const int* __restrict__ coords, long long n,
+                                                       const long long* __restrict__ d_n,
                                                        ConvGeom g, VxSlot* t, long long mask) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+  if (i >= rows_of(n, d_n)) return;
   const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  if (!site_ok(c, g)) return;   // never found by a lookup (lookups stay inside the grid)
   long long s = vx_hash_insert(t, mask, lin_idx(c.x, c.y, c.z, c.w, g.in_shape));
   t[s].a = (int)i;  // duplicate coordinates (invalid input) keep one of their rows
 }
@@ -43,12 +63,13 @@ __global__ __launch_bounds__(kThreads) void hash_build(const int* __restrict__ c
 // offsets is looked up (blockIdx.y = 0 .. K/2); a hit also fills the mirrored entry (each entry has exactly one
 // writer), the centre offset is the identity, and the caller pre-fills rows K/2+1 .. K-1 with -1.
 __global__ __launch_bounds__(kThreads) void subm_nbr(const int* __restrict__ coords, long long n,
+                                                     const long long* __restrict__ d_n,
                                                      ConvGeom g, const VxSlot* __restrict__ t,
                                                      long long mask, int* __restrict__ nbr,
                                                      long long ld) {
   const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
   const int k = blockIdx.y;
-  if (o >= n) return;
+  if (o >= rows_of(n, d_n)) return;
   if (2 * k + 1 == g.kvol) {
     nbr[(long long)k * ld + o] = (int)o;
     return;
@@ -68,10 +89,16 @@ __global__ __launch_bounds__(kThreads) void subm_nbr(const int* __restrict__ coo
 // races are benign and the result is deterministic). Device-scope atomicOr on a bitmap measured
 // 7.5 G marks/s on MI355X (1.2 ms per FHD step); bitmap_pack then folds 32 bytes into one word.
 __global__ __launch_bounds__(kThreads) void conv_mark(const int* __restrict__ coords, long long n,
-                                                      ConvGeom g, unsigned char* __restrict__ bytemap) {
+                                                      const long long* __restrict__ d_n,
+                                                      ConvGeom g, unsigned char* __restrict__ bytemap,
+                                                      long long* __restrict__ err) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+  if (i >= rows_of(n, d_n)) return;
   const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  if (!site_ok(c, g)) {
+    *err = 1;
+    return;
+  }
   for (int kz = 0; kz < g.k[0]; ++kz) {
     const int tz = c.y + g.p[0] - kz;
     if (tz < 0 || tz % g.s[0]) continue;
@@ -116,12 +143,12 @@ __global__ __launch_bounds__(kThreads) void bitmap_pack(const unsigned char* __r
 __global__ __launch_bounds__(kThreads) void conv_emit_coords(const unsigned* __restrict__ bitmap,
                                                              const int* __restrict__ base,
                                                              long long nwords, ConvGeom g,
-                                                             int* __restrict__ out_coords) {
+                                                             int* __restrict__ out_coords, long long cap_out) {
   long long w = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (w >= nwords) return;
   unsigned bits = bitmap[w];
   int row = base[w];
-  while (bits) {
+  while (bits && row < cap_out) {   // rows past the output capacity are dropped (the caller compares count and capacity)
     const int b = __ffs(bits) - 1;
     bits &= bits - 1;
     long long key = (w << 5) + b;
@@ -152,11 +179,17 @@ __global__ __launch_bounds__(kThreads) void rank_interleave(const unsigned* __re
 // outputs it feeds, finds their rows in the rank table and writes both tables. The output table
 // was pre-filled with -1; the transpose table gets every (k, i) entry written here (coalesced).
 __global__ __launch_bounds__(kThreads) void conv_pairs_from_inputs(
-    const int* __restrict__ coords, long long n, ConvGeom g, const uint2* __restrict__ rank,
-    int* __restrict__ nbr, long long ld, int* __restrict__ nbr_t, long long ld_t) {
+    const int* __restrict__ coords, long long n, const long long* __restrict__ d_n, ConvGeom g,
+    const uint2* __restrict__ rank, int* __restrict__ nbr, long long ld, long long cap_out,
+    int* __restrict__ nbr_t, long long ld_t) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+  if (i >= rows_of(n, d_n)) return;
   const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  if (!site_ok(c, g)) {           // reported by conv_mark; feeds nothing
+    if (nbr_t)
+      for (int k = 0; k < g.kvol; ++k) nbr_t[(long long)k * ld_t + i] = -1;
+    return;
+  }
   for (int kz = 0; kz < g.k[0]; ++kz) {
     const int tz = c.y + g.p[0] - kz;
     const bool vz = tz >= 0 && (tz % g.s[0]) == 0 && (tz / g.s[0]) < g.out_shape[0];
@@ -169,6 +202,7 @@ __global__ __launch_bounds__(kThreads) void conv_pairs_from_inputs(
         int row = -1;
         if (vy && tx >= 0 && (tx % g.s[2]) == 0 && (tx / g.s[2]) < g.out_shape[2]) {
           row = rank_lookup(rank, lin_idx(c.x, tz / g.s[0], ty / g.s[1], tx / g.s[2], g.out_shape));
+          if (row >= cap_out) row = -1;
           if (row >= 0) nbr[(long long)k * ld + row] = (int)i;
         }
         if (nbr_t) nbr_t[(long long)k * ld_t + i] = row;
@@ -179,11 +213,12 @@ __global__ __launch_bounds__(kThreads) void conv_pairs_from_inputs(
 
 // submanifold rulebook over a set that carries a rank table (outputs of a strided conv: sorted rows)
 __global__ __launch_bounds__(kThreads) void subm_nbr_ranked(const int* __restrict__ coords,
-                                                            long long n, ConvGeom g,
-                                                            const uint2* __restrict__ rank,
+                                                            long long n, const long long* __restrict__ d_n,
+                                                            ConvGeom g, const uint2* __restrict__ rank,
                                                             int* __restrict__ nbr, long long ld) {
   const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
   const int k = blockIdx.y;                          // first half of the offsets + centre (see subm_nbr)
+  n = rows_of(n, d_n);
   if (o >= n) return;
   if (2 * k + 1 == g.kvol) {
     nbr[(long long)k * ld + o] = (int)o;
@@ -193,8 +228,10 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_ranked(const int* __restric
   const int4 c = *reinterpret_cast<const int4*>(coords + 4 * o);
   const int z = c.y + kz - g.k[0] / 2, y = c.z + ky - g.k[1] / 2, x = c.w + kx - g.k[2] / 2;
   int r = -1;
-  if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2])
+  if (c.x >= 0 && c.x < g.batch && z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 &&
+      x < g.in_shape[2])
     r = rank_lookup(rank, lin_idx(c.x, z, y, x, g.in_shape));
+  if (r >= n) r = -1;             // a rank table built for more rows than this call covers (capacity overflow)
   nbr[(long long)k * ld + o] = r;
   if (r >= 0) nbr[(long long)(g.kvol - 1 - k) * ld + r] = (int)o;
 }
@@ -294,8 +331,9 @@ __global__ __launch_bounds__(kThreads) void permute_table(const int* __restrict_
 }
 
 int fill_geom(ConvGeom* g, const int32_t* in_shape, const int32_t* ksize, const int32_t* stride,
-              const int32_t* pad, bool subm) {
+              const int32_t* pad, bool subm, int batch) {
   g->kvol = 1;
+  g->batch = batch;
   for (int d = 0; d < 3; ++d) {
     g->in_shape[d] = in_shape[d];
     g->k[d] = ksize[d];
@@ -366,24 +404,24 @@ extern "C" size_t vx_rulebook_workspace_bytes(int64_t n_in, int32_t batch,
   return carve(nullptr, n_in, batch, out_shape).bytes;
 }
 
-static int32_t build_table(const int32_t* d_coords, int64_t n, const ConvGeom& g, const RbWs& w,
-                           hipStream_t stream) {
+static int32_t build_table(const int32_t* d_coords, int64_t n, const long long* d_n, const ConvGeom& g,
+                           const RbWs& w, hipStream_t stream) {
   hash_clear<<<(unsigned)vx_cdiv(w.cap, kThreads), kThreads, 0, stream>>>(w.table, w.cap);
   VX_LAUNCH_CHECK();
-  hash_build<<<(unsigned)vx_cdiv(n, kThreads), kThreads, 0, stream>>>(d_coords, n, g, w.table,
+  hash_build<<<(unsigned)vx_cdiv(n, kThreads), kThreads, 0, stream>>>(d_coords, n, d_n, g, w.table,
                                                                       w.cap - 1);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }
 
-extern "C" int32_t vx_rulebook_subm(const int32_t* d_coords, int64_t n, int32_t batch,
-                                    const int32_t* shape, const int32_t* ksize, int32_t* d_nbr,
-                                    int64_t nbr_ld, void* d_ws, size_t ws_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// n = row count (d_n == NULL) or capacity (d_n = device row count)
+static int32_t subm_impl(const int32_t* d_coords, int64_t n, const int64_t* d_n, int32_t batch,
+                         const int32_t* shape, const int32_t* ksize, int32_t* d_nbr, int64_t nbr_ld,
+                         void* d_ws, size_t ws_bytes, hipStream_t stream) {
   VX_REQUIRE(shape && ksize && d_ws, "rulebook_subm: null pointer");
   VX_REQUIRE(n >= 0 && n < (1ll << 31) && batch >= 1, "rulebook_subm: bad n/batch");
   ConvGeom g;
-  VX_REQUIRE(fill_geom(&g, shape, ksize, nullptr, nullptr, true) == 0,
+  VX_REQUIRE(fill_geom(&g, shape, ksize, nullptr, nullptr, true, batch) == 0,
              "rulebook_subm: bad geometry (odd kernel sizes <= 125 offsets required)");
   if (n == 0) return VX_OK;
   VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm: bad table pointer / stride");
@@ -392,13 +430,59 @@ extern "C" int32_t vx_rulebook_subm(const int32_t* d_coords, int64_t n, int32_t 
     vx_set_error("rulebook_subm: workspace %zu < %zu", ws_bytes, w.bytes);
     return VX_ERR_WORKSPACE;
   }
-  int32_t rc = build_table(d_coords, n, g, w, stream);
+  int32_t rc = build_table(d_coords, n, (const long long*)d_n, g, w, stream);
   if (rc) return rc;
   const int half = g.kvol / 2;                       // odd kvol: offsets 0..half-1 mirror half+1..kvol-1
   if (half > 0)
     VX_HIP(hipMemsetAsync(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream));
   dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)(half + 1));
-  subm_nbr<<<grid, kThreads, 0, stream>>>(d_coords, n, g, w.table, w.cap - 1, d_nbr, nbr_ld);
+  subm_nbr<<<grid, kThreads, 0, stream>>>(d_coords, n, (const long long*)d_n, g, w.table, w.cap - 1, d_nbr,
+                                          nbr_ld);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" int32_t vx_rulebook_subm(const int32_t* d_coords, int64_t n, int32_t batch,
+                                    const int32_t* shape, const int32_t* ksize, int32_t* d_nbr,
+                                    int64_t nbr_ld, void* d_ws, size_t ws_bytes, void* stream) {
+  return subm_impl(d_coords, n, nullptr, batch, shape, ksize, d_nbr, nbr_ld, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int32_t vx_rulebook_subm_dn(const int32_t* d_coords, const int64_t* d_n, int64_t cap, int32_t batch,
+                                       const int32_t* shape, const int32_t* ksize, int32_t* d_nbr,
+                                       int64_t nbr_ld, void* d_ws, size_t ws_bytes, void* stream) {
+  VX_REQUIRE(d_n && cap >= 1, "rulebook_subm_dn: need the device row count and a capacity >= 1");
+  return subm_impl(d_coords, cap, d_n, batch, shape, ksize, d_nbr, nbr_ld, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+// phase 1 of the strided conv: occupancy of the output grid -> sorted rank {bits, base} per 32 cells, total -> d_total
+static int32_t conv_count_impl(const int32_t* d_coords, int64_t n_in, const int64_t* d_n_in, const ConvGeom& g,
+                               const RbWs& w, int64_t* d_total, long long* d_err, hipStream_t stream) {
+  VX_HIP(hipMemsetAsync(w.bytemap, 0, 32 * (size_t)w.nwords, stream));
+  conv_mark<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(d_coords, n_in, (const long long*)d_n_in, g,
+                                                                        w.bytemap, d_err);
+  VX_LAUNCH_CHECK();
+  bitmap_pack<<<(unsigned)vx_cdiv(w.nwords, kThreads), kThreads, 0, stream>>>(w.bytemap, w.nwords,
+                                                                              w.bitmap, w.base);
+  VX_LAUNCH_CHECK();
+  return vx_scan_exclusive_i32(w.base, w.base, w.nwords, d_total, w.scan_ws, w.scan_bytes, stream);
+}
+
+// phase 2: output coordinates, rank table, neighbour table(s). cap_out = rows the output buffers hold.
+static int32_t conv_emit_impl(const int32_t* d_coords, int64_t n_in, const int64_t* d_n_in, const ConvGeom& g,
+                              const RbWs& w, int64_t cap_out, int32_t* d_out_coords, int32_t* d_nbr,
+                              int64_t nbr_ld, int32_t* d_nbr_t, int64_t nbr_t_ld, void* d_rank,
+                              hipStream_t stream) {
+  const unsigned gw = (unsigned)vx_cdiv(w.nwords, kThreads);
+  conv_emit_coords<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, g, d_out_coords, cap_out);
+  VX_LAUNCH_CHECK();
+  // rank table {bits, base}: caller's buffer when it wants to keep it, else the hash area of the workspace
+  uint2* rank = d_rank ? (uint2*)d_rank : (uint2*)w.rank_tmp;
+  rank_interleave<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, rank);
+  VX_LAUNCH_CHECK();
+  VX_HIP(hipMemsetAsync(d_nbr, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_ld, stream));
+  conv_pairs_from_inputs<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(
+      d_coords, n_in, (const long long*)d_n_in, g, rank, d_nbr, nbr_ld, cap_out, d_nbr_t, nbr_t_ld);
   VX_LAUNCH_CHECK();
   return VX_OK;
 }
@@ -413,7 +497,7 @@ extern "C" int32_t vx_rulebook_conv_count(const int32_t* d_coords, int64_t n_in,
              "rulebook_conv_count: null pointer");
   VX_REQUIRE(n_in >= 0 && n_in < (1ll << 31) && batch >= 1, "rulebook_conv_count: bad n/batch");
   ConvGeom g;
-  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false) == 0,
+  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false, batch) == 0,
              "rulebook_conv_count: bad geometry");
   for (int d = 0; d < 3; ++d) out_shape[d] = g.out_shape[d];
   *h_n_out = 0;
@@ -424,18 +508,18 @@ extern "C" int32_t vx_rulebook_conv_count(const int32_t* d_coords, int64_t n_in,
     vx_set_error("rulebook_conv_count: workspace %zu < %zu", ws_bytes, w.bytes);
     return VX_ERR_WORKSPACE;
   }
-  VX_HIP(hipMemsetAsync(w.bytemap, 0, 32 * (size_t)w.nwords, stream));
-  conv_mark<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(d_coords, n_in, g,
-                                                                        w.bytemap);
-  VX_LAUNCH_CHECK();
-  bitmap_pack<<<(unsigned)vx_cdiv(w.nwords, kThreads), kThreads, 0, stream>>>(w.bytemap, w.nwords,
-                                                                              w.bitmap, w.base);
-  VX_LAUNCH_CHECK();
-  int32_t rc = vx_scan_exclusive_i32(w.base, w.base, w.nwords, (int64_t*)w.total, w.scan_ws,
-                                     w.scan_bytes, stream);
+  VX_HIP(hipMemsetAsync(w.total, 0, 16, stream));          // {output rows, error word}
+  int32_t rc = conv_count_impl(d_coords, n_in, nullptr, g, w, (int64_t*)w.total, w.total + 1, stream);
   if (rc) return rc;
-  VX_HIP(hipMemcpyAsync(h_n_out, w.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  int64_t h[2] = {0, 0};
+  VX_HIP(hipMemcpyAsync(h, w.total, sizeof(h), hipMemcpyDeviceToHost, stream));
   VX_HIP(hipStreamSynchronize(stream));
+  if (h[1]) {
+    vx_set_error("rulebook_conv_count: a coordinate lies outside batch %d x grid [%d,%d,%d] (batch index or site out "
+                 "of range)", batch, in_shape[0], in_shape[1], in_shape[2]);
+    return VX_ERR_ARG;
+  }
+  *h_n_out = h[0];
   return VX_OK;
 }
 
@@ -448,7 +532,7 @@ extern "C" int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, 
   hipStream_t stream = (hipStream_t)stream_;
   VX_REQUIRE(in_shape && ksize && stride && pad && d_ws, "rulebook_conv_emit: null pointer");
   ConvGeom g;
-  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false) == 0,
+  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false, batch) == 0,
              "rulebook_conv_emit: bad geometry");
   if (n_in == 0 || n_out == 0) return VX_OK;
   VX_REQUIRE(d_coords && d_out_coords && d_nbr && nbr_ld >= n_out,
@@ -459,18 +543,34 @@ extern "C" int32_t vx_rulebook_conv_emit(const int32_t* d_coords, int64_t n_in, 
     vx_set_error("rulebook_conv_emit: workspace %zu < %zu", ws_bytes, w.bytes);
     return VX_ERR_WORKSPACE;
   }
-  const unsigned gw = (unsigned)vx_cdiv(w.nwords, kThreads);
-  conv_emit_coords<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, g, d_out_coords);
-  VX_LAUNCH_CHECK();
-  // rank table {bits, base}: caller's buffer when it wants to keep it, else the hash area of the workspace
-  uint2* rank = d_rank ? (uint2*)d_rank : (uint2*)w.rank_tmp;
-  rank_interleave<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, rank);
-  VX_LAUNCH_CHECK();
-  VX_HIP(hipMemsetAsync(d_nbr, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_ld, stream));
-  conv_pairs_from_inputs<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(
-      d_coords, n_in, g, rank, d_nbr, nbr_ld, d_nbr_t, nbr_t_ld);
-  VX_LAUNCH_CHECK();
-  return VX_OK;
+  return conv_emit_impl(d_coords, n_in, nullptr, g, w, n_out, d_out_coords, d_nbr, nbr_ld, d_nbr_t, nbr_t_ld,
+                        d_rank, stream);
+}
+
+extern "C" int32_t vx_rulebook_conv_dn(const int32_t* d_coords, const int64_t* d_n_in, int64_t cap_in,
+                                       int32_t batch, const int32_t* in_shape, const int32_t* ksize,
+                                       const int32_t* stride, const int32_t* pad, int32_t* out_shape,
+                                       int64_t cap_out, int32_t* d_out_coords, int64_t* d_n_out,
+                                       int32_t* d_nbr, int64_t nbr_ld, void* d_rank, int64_t* d_err,
+                                       void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(in_shape && ksize && stride && pad && out_shape && d_ws && d_n_in && d_n_out && d_err,
+             "rulebook_conv_dn: null pointer");
+  VX_REQUIRE(cap_in >= 1 && cap_in < (1ll << 31) && cap_out >= 1 && cap_out < (1ll << 31) && batch >= 1,
+             "rulebook_conv_dn: bad capacities / batch");
+  ConvGeom g;
+  VX_REQUIRE(fill_geom(&g, in_shape, ksize, stride, pad, false, batch) == 0, "rulebook_conv_dn: bad geometry");
+  for (int d = 0; d < 3; ++d) out_shape[d] = g.out_shape[d];
+  VX_REQUIRE(d_coords && d_out_coords && d_nbr && nbr_ld >= cap_out, "rulebook_conv_dn: bad output pointers / stride");
+  RbWs w = carve(d_ws, cap_in, batch, g.out_shape);
+  if (ws_bytes < w.bytes) {
+    vx_set_error("rulebook_conv_dn: workspace %zu < %zu", ws_bytes, w.bytes);
+    return VX_ERR_WORKSPACE;
+  }
+  int32_t rc = conv_count_impl(d_coords, cap_in, d_n_in, g, w, d_n_out, (long long*)d_err, stream);
+  if (rc) return rc;
+  return conv_emit_impl(d_coords, cap_in, d_n_in, g, w, cap_out, d_out_coords, d_nbr, nbr_ld, nullptr, 0, d_rank,
+                        stream);
 }
 
 extern "C" size_t vx_rank_table_bytes(int32_t batch, const int32_t* shape) {
@@ -478,15 +578,13 @@ extern "C" size_t vx_rank_table_bytes(int32_t batch, const int32_t* shape) {
   return (size_t)((cells + 31) / 32) * 8;
 }
 
-extern "C" int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, int32_t batch,
-                                           const int32_t* shape, const int32_t* ksize,
-                                           const void* d_rank, int32_t* d_nbr, int64_t nbr_ld,
-                                           void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int32_t subm_ranked_impl(const int32_t* d_coords, int64_t n, const int64_t* d_n, int32_t batch,
+                                const int32_t* shape, const int32_t* ksize, const void* d_rank,
+                                int32_t* d_nbr, int64_t nbr_ld, hipStream_t stream) {
   VX_REQUIRE(shape && ksize && d_rank, "rulebook_subm_ranked: null pointer");
   VX_REQUIRE(n >= 0 && n < (1ll << 31) && batch >= 1, "rulebook_subm_ranked: bad n/batch");
   ConvGeom g;
-  VX_REQUIRE(fill_geom(&g, shape, ksize, nullptr, nullptr, true) == 0,
+  VX_REQUIRE(fill_geom(&g, shape, ksize, nullptr, nullptr, true, batch) == 0,
              "rulebook_subm_ranked: bad geometry (odd kernel sizes <= 125 offsets required)");
   if (n == 0) return VX_OK;
   VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm_ranked: bad table pointer / stride");
@@ -494,9 +592,25 @@ extern "C" int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, i
   if (half > 0)
     VX_HIP(hipMemsetAsync(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream));
   dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)(half + 1));
-  subm_nbr_ranked<<<grid, kThreads, 0, stream>>>(d_coords, n, g, (const uint2*)d_rank, d_nbr, nbr_ld);
+  subm_nbr_ranked<<<grid, kThreads, 0, stream>>>(d_coords, n, (const long long*)d_n, g, (const uint2*)d_rank,
+                                                 d_nbr, nbr_ld);
   VX_LAUNCH_CHECK();
   return VX_OK;
+}
+
+extern "C" int32_t vx_rulebook_subm_ranked(const int32_t* d_coords, int64_t n, int32_t batch,
+                                           const int32_t* shape, const int32_t* ksize,
+                                           const void* d_rank, int32_t* d_nbr, int64_t nbr_ld,
+                                           void* stream) {
+  return subm_ranked_impl(d_coords, n, nullptr, batch, shape, ksize, d_rank, d_nbr, nbr_ld, (hipStream_t)stream);
+}
+
+extern "C" int32_t vx_rulebook_subm_ranked_dn(const int32_t* d_coords, const int64_t* d_n, int64_t cap,
+                                              int32_t batch, const int32_t* shape, const int32_t* ksize,
+                                              const void* d_rank, int32_t* d_nbr, int64_t nbr_ld,
+                                              void* stream) {
+  VX_REQUIRE(d_n && cap >= 1, "rulebook_subm_ranked_dn: need the device row count and a capacity >= 1");
+  return subm_ranked_impl(d_coords, cap, d_n, batch, shape, ksize, d_rank, d_nbr, nbr_ld, (hipStream_t)stream);
 }
 
 extern "C" int32_t vx_rulebook_sort_rows(const int32_t* d_nbr, int64_t nbr_ld, int32_t kvol,

@@ -33,13 +33,27 @@ struct VoxGeom {
   int n_frames;
   int batch_idx0;             // frame f gets batch index batch_idx0 + f
   long long off[kMaxFrames + 1];  // point ranges of the frames (frame-major concatenation)
+  // "_dn" form: the ranges live on the device (int64[n_frames + 1]) and `off` is unused; the point count is
+  // d_off[n_frames], the host-side n only the capacity the grids were sized for
+  const long long* d_off;
+  long long row_cap;          // "_dn" form: rows the outputs hold (voxels past it are dropped, the count is not clamped)
 };
+
+__device__ __forceinline__ long long frame_off(const VoxGeom& g, int f) { return g.d_off ? g.d_off[f] : g.off[f]; }
+
+__device__ __forceinline__ long long points_of(const VoxGeom& g, long long n) {
+  if (g.d_off) {
+    const long long d = g.d_off[g.n_frames];
+    n = d < n ? (d > 0 ? d : 0) : n;
+  }
+  return n;
+}
 
 __device__ __forceinline__ int frame_of(const VoxGeom& g, long long i) {
   int lo = 0, hi = g.n_frames;  // off[lo] <= i < off[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (i >= g.off[mid]) lo = mid; else hi = mid;
+    if (i >= frame_off(g, mid)) lo = mid; else hi = mid;
   }
   return lo;
 }
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void vox_insert(const float* __restrict__
                                                        int nf, VoxGeom g, VxSlot* t,
                                                        long long mask, int* __restrict__ slot_of) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+  if (i >= points_of(g, n)) return;
   const float* p = pts + i * nf;
   float c[3];
   bool ok = true;
@@ -82,9 +96,13 @@ __global__ __launch_bounds__(kThreads) void vox_insert(const float* __restrict__
 
 __global__ __launch_bounds__(kThreads) void vox_flag(const VxSlot* __restrict__ t,
                                                      const int* __restrict__ slot_of, long long n,
-                                                     int* __restrict__ flag) {
+                                                     VoxGeom g, int* __restrict__ flag) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
+  if (i >= points_of(g, n)) {      // capacity beyond the device point count: the scan runs over it
+    flag[i] = 0;
+    return;
+  }
   int s = slot_of[i];
   flag[i] = (s >= 0 && t[s].a == (int)i) ? 1 : 0;
 }
@@ -102,10 +120,10 @@ __global__ __launch_bounds__(kThreads) void vox_assign(VxSlot* t, const int* __r
                                                        long long* __restrict__ num_voxels) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i == 0) *num_voxels = (*total < max_voxels) ? *total : max_voxels;
-  if (i >= n || !flag[i]) return;
+  if (i >= points_of(g, n) || !flag[i]) return;
   const int s = slot_of[i];
   const int v = pos[i];
-  if (v >= max_voxels) {
+  if (v >= max_voxels || v >= g.row_cap) {
     t[s].a = -1;
     return;
   }
@@ -125,11 +143,12 @@ __global__ __launch_bounds__(kThreads) void vox_assign(VxSlot* t, const int* __r
 
 __global__ __launch_bounds__(kThreads) void vox_fill_lists(const VxSlot* __restrict__ t,
                                                            const int* __restrict__ slot_of,
-                                                           long long n, const int* __restrict__ off,
+                                                           long long n, VoxGeom g,
+                                                           const int* __restrict__ off,
                                                            int* __restrict__ fill,
                                                            int* __restrict__ plist) {
   long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
+  if (i >= points_of(g, n)) return;
   const int s = slot_of[i];
   if (s < 0) return;
   const int v = t[s].a;
@@ -144,10 +163,11 @@ __global__ __launch_bounds__(kThreads) void vox_gather(const float* __restrict__
                                                        const int* __restrict__ cntv,
                                                        const int* __restrict__ plist,
                                                        const long long* __restrict__ num_voxels,
+                                                       long long row_cap,
                                                        int max_points, float* __restrict__ voxels,
                                                        float* __restrict__ mean) {
   const long long v = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (v >= *num_voxels) return;
+  if (v >= *num_voxels || v >= row_cap) return;
   const int b = off[v], cnt = cntv[v];
   const int keep = cnt < max_points ? cnt : max_points;
   float sum[8];
@@ -186,8 +206,10 @@ __global__ void vox_frame_counts(const int* __restrict__ pos, long long n, VoxGe
                                  const long long* __restrict__ total, long long* __restrict__ counts) {
   const int f = threadIdx.x;
   if (f >= g.n_frames) return;
-  const long long a = g.off[f] < n ? pos[g.off[f]] : *total;
-  const long long b = g.off[f + 1] < n ? pos[g.off[f + 1]] : *total;
+  n = points_of(g, n);
+  const long long o0 = frame_off(g, f), o1 = frame_off(g, f + 1);
+  const long long a = o0 < n ? pos[o0] : *total;
+  const long long b = o1 < n ? pos[o1] : *total;
   counts[f] = b - a;
 }
 
@@ -235,7 +257,7 @@ extern "C" size_t vx_voxelize_workspace_bytes(int64_t n_points) {
 static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const float* voxel_size,
                              const float* range, int32_t max_points, int64_t max_voxels,
                              int32_t batch_idx, int32_t n_frames, const int64_t* frame_offsets,
-                             int32_t* d_coords, int32_t* d_num_points, float* d_voxels,
+                             const int64_t* d_frame_offsets, int32_t* d_coords, int32_t* d_num_points, float* d_voxels,
                              float* d_mean, int64_t cap, int64_t* d_num_voxels,
                              int64_t* h_num_voxels, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -245,7 +267,8 @@ static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const
   VX_REQUIRE(voxel_size && range && d_coords && d_num_points && d_num_voxels && d_ws,
              "voxelize: null pointer");
   VX_REQUIRE(n == 0 || d_points, "voxelize: null points");
-  const int64_t need_cap = n < max_voxels ? n : max_voxels;
+  int64_t need_cap = n < max_voxels ? n : max_voxels;
+  if (d_frame_offsets && cap < need_cap) need_cap = cap;   // "_dn": rows past `cap` are dropped, the count says so
   if (cap < need_cap) {
     vx_set_error("voxelize: output capacity %lld < min(n_points, max_voxels) = %lld",
                  (long long)cap, (long long)need_cap);
@@ -259,7 +282,10 @@ static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const
   VoxGeom g;
   g.n_frames = n_frames;
   g.batch_idx0 = batch_idx;
-  for (int f = 0; f <= n_frames; ++f) g.off[f] = frame_offsets ? frame_offsets[f] : (f ? n : 0);
+  g.d_off = (const long long*)d_frame_offsets;
+  g.row_cap = cap;
+  for (int f = 0; f <= n_frames; ++f)
+    g.off[f] = d_frame_offsets ? 0 : (frame_offsets ? frame_offsets[f] : (f ? n : 0));
   long long cells = n_frames;
   for (int d = 0; d < 3; ++d) {
     g.lo[d] = range[d];
@@ -281,7 +307,7 @@ static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const
     VX_LAUNCH_CHECK();
     vox_insert<<<gp, kThreads, 0, stream>>>(d_points, n, nf, g, w.table, w.cap - 1, w.slot_of);
     VX_LAUNCH_CHECK();
-    vox_flag<<<gp, kThreads, 0, stream>>>(w.table, w.slot_of, n, w.flag);
+    vox_flag<<<gp, kThreads, 0, stream>>>(w.table, w.slot_of, n, g, w.flag);
     VX_LAUNCH_CHECK();
     int32_t rc = vx_scan_exclusive_i32(w.flag, w.pos, n, (int64_t*)w.total, w.scan_ws,
                                        w.scan_bytes, stream);
@@ -306,10 +332,10 @@ static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const
       rc = vx_scan_exclusive_i32(w.cntv, w.off, need_cap, nullptr, w.scan_ws, w.scan_bytes,
                                  stream);
       if (rc) return rc;
-      vox_fill_lists<<<gp, kThreads, 0, stream>>>(w.table, w.slot_of, n, w.off, w.fill, w.plist);
+      vox_fill_lists<<<gp, kThreads, 0, stream>>>(w.table, w.slot_of, n, g, w.off, w.fill, w.plist);
       VX_LAUNCH_CHECK();
       vox_gather<<<(unsigned)vx_cdiv(need_cap, kThreads), kThreads, 0, stream>>>(
-          d_points, nf, w.off, w.cntv, w.plist, (const long long*)d_num_voxels, max_points,
+          d_points, nf, w.off, w.cntv, w.plist, (const long long*)d_num_voxels, (long long)cap, max_points,
           d_voxels, d_mean);
       VX_LAUNCH_CHECK();
     }
@@ -330,7 +356,7 @@ extern "C" int32_t vx_voxelize_hard(const float* d_points, int64_t n, int32_t nf
                                     int64_t* h_num_voxels, void* d_ws, size_t ws_bytes,
                                     void* stream) {
   return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, max_voxels, batch_idx, 1,
-                       nullptr, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
+                       nullptr, nullptr, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
                        h_num_voxels, d_ws, ws_bytes, stream);
 }
 
@@ -353,8 +379,22 @@ extern "C" int32_t vx_voxelize_hard_batch(const float* d_points, int32_t n_frame
   }
   const int64_t n = frame_offsets[n_frames];
   return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, (int64_t)1 << 40, 0, n_frames,
-                       frame_offsets, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
+                       frame_offsets, nullptr, d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels,
                        h_num_voxels, d_ws, ws_bytes, stream);
+}
+
+extern "C" int32_t vx_voxelize_hard_batch_dn(const float* d_points, int32_t n_frames,
+                                             const int64_t* d_frame_offsets, int64_t cap_points,
+                                             int32_t nf, const float* voxel_size, const float* range,
+                                             int32_t max_points, int32_t* d_coords,
+                                             int32_t* d_num_points, float* d_mean, int64_t cap,
+                                             int64_t* d_num_voxels, void* d_ws, size_t ws_bytes,
+                                             void* stream) {
+  VX_REQUIRE(n_frames >= 1 && n_frames <= kMaxFrames && d_frame_offsets && cap_points >= 1 && cap >= 1,
+             "voxelize_batch_dn: 1 <= n_frames <= 64, device frame offsets and capacities >= 1 required");
+  return voxelize_impl(d_points, cap_points, nf, voxel_size, range, max_points, (int64_t)1 << 40, 0, n_frames,
+                       nullptr, d_frame_offsets, d_coords, d_num_points, nullptr, d_mean, cap, d_num_voxels,
+                       nullptr, d_ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -422,7 +462,7 @@ extern "C" int32_t vx_voxelize_hard_static(const float* d_points, int64_t n, int
   if (int32_t rc = scratch_address(&ws)) return rc;
   // voxelize_impl re-initialises everything it reads (table, counters) on every call, so the contents the last
   // call left behind do not matter; it launches kernels, memsets and (only when h_num_voxels != NULL) one D2H copy.
-  return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, max_voxels, batch_idx, 1, nullptr,
+  return voxelize_impl(d_points, n, nf, voxel_size, range, max_points, max_voxels, batch_idx, 1, nullptr, nullptr,
                        d_coords, d_num_points, d_voxels, d_mean, cap, d_num_voxels, h_num_voxels, ws,
                        kStaticBytes, stream);
 }

@@ -3,6 +3,8 @@ with BatchNorm1d(eval) + bias + ReLU + residual folded into the conv kernel's ep
 (scn.py:82-98 collapses from 2 GEMM sets + 4 elementwise passes to 2 launches per block) and all
 rulebooks of a frame built before the feature pass (they depend on coordinates only).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -36,7 +38,8 @@ def _compile_sequential(seq, dev, dtype):
         s = _Step()
         s.kind = "subm" if conv.subm else "conv"
         s.w = conv.weight.detach().to(dev, dtype).contiguous()
-        s.w32 = conv.weight.detach().to(dev, torch.float32).contiguous() if conv.in_channels % 8 else None
+        # fp32 copy for layers that may be fed fp32 features while the engine runs bf16 (the voxelizer's means)
+        s.w32 = conv.weight.detach().to(dev, torch.float32).contiguous() if dtype != torch.float32 else s.w
         s.wpack = None   # ops.pack_weight(s.w) would select the streaming-W kernel (slower end to end)
         s.bias = conv.bias.detach().float().to(dev).contiguous() if conv.bias is not None else None
         s.scale, s.shift = _fold_bn(bn, dev) if bn is not None else (None, None)
@@ -105,14 +108,164 @@ def _run(steps, st, geom_only=False):
     return st
 
 
-class FusedBackbone:
-    """Eval-mode forward of SpMiddleResNetFHD / MultiViewBackbone with fused epilogues."""
+def _run_dn(steps, st, caps, counts, slot, err, geom_only=False):
+    """_run with device-resident row counts (vista_amd.ops_dn): no host sync anywhere. `caps[j]` / `counts[slot + j]`
+    = output capacity / count slot of the j-th strided conv met (in call order over the whole plan)."""
+    from . import ops_dn
+    st = _State(st.feat, st.idx, st.shape, st.batch, st.cache, st.rank)
+    st.n = st.cache["n", id(st.idx)]
+    identity = None
+    for s in steps:
+        if s.kind == "subm":
+            key = (s.key, id(st.idx))
+            rb = st.cache.get(key)
+            if rb is None:
+                rb = ops_dn.rulebook_subm_dn(st.idx, st.n, st.batch, st.shape, s.ksize, rank=st.rank)
+                st.cache[key] = rb
+        else:
+            key = ("conv", id(st.idx), tuple(s.ksize), tuple(s.stride), tuple(s.padding))
+            rb = st.cache.get(key)
+            if rb is None:
+                j = st.cache["next_conv"]
+                st.cache["next_conv"] = j + 1
+                rb = ops_dn.rulebook_conv_dn(st.idx, st.n, st.batch, st.shape, s.ksize, s.stride, s.padding,
+                                             caps[j], counts[slot + j:slot + j + 1], err)
+                st.cache[key] = rb
+                st.cache["n", id(rb.out_indices)] = rb.n_out
+        if s.residual == "save":
+            identity = st.feat
+        res = identity if s.residual == "add" else None
+        if not geom_only:
+            w = s.w
+            if st.feat.dtype != w.dtype:
+                w = s.w32
+            st.feat = ops_dn.conv_fwd_dn(st.feat, w, rb, bias=s.bias, scale=s.scale, shift=s.shift, residual=res,
+                                         relu=s.relu)
+            if st.feat.dtype != s.w.dtype:
+                st.feat = st.feat.to(s.w.dtype)
+        if s.kind == "conv":
+            st.idx, st.shape, st.rank, st.n = rb.out_indices, rb.out_shape, rb.out_rank, rb.n_out
+    return st
 
-    def __init__(self, module, dtype=torch.float32, eager=True):
+
+class FramePlan:
+    """Voxelization + backbone for `n_frames` clouds without one host synchronisation inside the step.
+
+    Every buffer has a fixed capacity and every row count stays on the device (the "_dn" entry points). The eager
+    path waits for the GPU five times per step (the voxel count and the output row count of each strided conv) and
+    the GPU idles while the host catches up after each wait; here the ~120 launches of a step are either
+      "queued": issued back to back on the caller's stream (the host runs ahead of the GPU), or
+      "graph" : recorded once in a HIP graph and replayed with a single graph launch (no Python dispatch at all).
+    After the step the counts come back in one small copy; a count above its capacity means rows were dropped, and
+    the caller (FusedBackbone.forward_frames) re-plans with larger capacities. Results are bitwise those of the eager
+    path (tests/test_gpu_plan.py)."""
+
+    COUNT_SLOTS = 16     # strided convs a plan may hold
+
+    def __init__(self, engine, gen, n_frames, grid, cap_points, cap_rows, caps, dev):
+        self.engine, self.gen, self.n_frames, self.grid = engine, gen, int(n_frames), list(grid)
+        self.cap_points, self.cap_rows, self.caps = int(cap_points), int(cap_rows), [int(c) for c in caps]
+        if len(self.caps) > self.COUNT_SLOTS:
+            raise ValueError("too many strided convolutions for one plan")
+        self.dev = dev
+        nf = self.n_frames
+        self.slot = 2 + nf                                   # counts: [err, total voxels, per frame ..., conv outputs ...]
+        self.counts = torch.zeros((self.slot + self.COUNT_SLOTS,), dtype=torch.int64, device=dev)
+        self.h_counts = torch.zeros_like(self.counts, device="cpu").pin_memory()
+        self.points = torch.zeros((self.cap_points, 5), dtype=torch.float32, device=dev)
+        self.offsets = torch.zeros((nf + 1,), dtype=torch.int64, device=dev)
+        self.h_offsets = torch.zeros((nf + 1,), dtype=torch.int64).pin_memory()
+        self.graph = None
+        self.out = None
+
+    def _forward(self):
+        from . import ops_dn
+        e, g = self.engine, self.gen
+        mean, coords, _ = ops_dn.voxelize_batch_dn(self.points, self.offsets, self.n_frames, g.voxel_size,
+                                                   g.point_cloud_range, g.max_num_points_per_voxel, self.cap_rows,
+                                                   self.counts[1:2 + self.n_frames])
+        sparse_shape = [int(v) for v in (np.array(self.grid[::-1]) + [1, 0, 0])]
+        cache = {"next_conv": 0, ("n", id(coords)): self.counts[1:2]}
+        st = _State(mean, coords, sparse_shape, self.n_frames, cache)
+        args = (self.caps, self.counts, self.slot, self.counts[0:1])
+        from . import ops_dn as od
+        mid = _run_dn(e.middle, st, *args)
+        if e.kind == "SpMiddleResNetFHD":
+            d = od.to_dense_dn(mid.feat, mid.idx, mid.n, mid.batch, mid.shape)
+            n, c, dd, h, w = d.shape
+            return d.view(n, c * dd, h, w) if e.mode == "bev" else d
+        b = _run_dn(e.bev, mid, *args)
+        bev = od.to_dense_dn(b.feat, b.idx, b.n, b.batch, b.shape)
+        n, c, d, h, w = bev.shape
+        bev = bev.view(n, c * d, h, w)
+        r = _run_dn(e.rv, mid, *args)
+        rv = od.to_dense_dn(r.feat, r.idx, r.n, r.batch, r.shape)
+        n, c, d, h, w = rv.shape
+        rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)
+        return bev, rv
+
+    def capture(self):
+        """One un-captured pass (loads kernels, sets function attributes, fills the allocator), then the capture."""
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            self._forward()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+            self.out = self._forward()
+        return self
+
+    def stage(self, frames):
+        """Copy the clouds into the plan's input buffer and upload their point ranges (stream-ordered, no sync)."""
+        off = 0
+        self.h_offsets[0] = 0
+        for i, f in enumerate(frames):
+            n = f.shape[0]
+            self.points[off:off + n].copy_(f, non_blocking=True)
+            off += n
+            self.h_offsets[i + 1] = off
+        self.offsets.copy_(self.h_offsets, non_blocking=True)
+
+    def replay(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:                       # "queued": the same launch sequence straight onto the current stream
+            with torch.no_grad():
+                self.out = self._forward()
+        self.h_counts.copy_(self.counts, non_blocking=True)
+
+    def overflow(self):
+        """After a stream synchronisation: None if every count fits, else the capacities this input needs."""
+        h = self.h_counts.tolist()
+        if h[0]:
+            raise ops.L.VxError("a voxel coordinate lies outside batch x grid (vx_rulebook_conv_dn error word)")
+        need_rows, need = h[1], h[self.slot:self.slot + len(self.caps)]
+        if need_rows <= self.cap_rows and all(n <= c for n, c in zip(need, self.caps)):
+            return None
+        return need_rows, need
+
+
+class FusedBackbone:
+    """Eval-mode forward of SpMiddleResNetFHD / MultiViewBackbone with fused epilogues.
+
+    __call__(voxel_features, coors, batch_size, input_shape) is the reference's backbone signature (scn.py:367,
+    multiview.py:88) on per-layer launches. forward_frames(generator, clouds, grid) runs voxelization + backbone from
+    raw clouds; unless the engine was built with eager=True it goes through a captured FramePlan."""
+
+    HEADROOM = 1.125      # capacity = observed count x this, rounded up to 1024 rows
+
+    def __init__(self, module, dtype=torch.float32, eager=False, dispatch=None):
         dev = next(module.parameters()).device
+        self.dev = dev
         self.kind = type(module).__name__
         self.dtype = dtype
         self.eager = bool(eager)
+        # how forward_frames issues a step: "queued" (sync-free launches on the stream) or "graph" (captured HIP graph)
+        self.dispatch = dispatch or os.environ.get("VX_DISPATCH", "queued")
+        if self.dispatch not in ("queued", "graph"):
+            raise ValueError("dispatch must be 'queued' or 'graph'")
         self.mode = getattr(module, "mode", "bev")
         self.middle = _compile_sequential(module.middle_conv, dev, dtype)
         if self.kind == "MultiViewBackbone":
@@ -120,14 +273,87 @@ class FusedBackbone:
             self.rv = _compile_sequential(module.rv_conv, dev, dtype)
         elif self.kind != "SpMiddleResNetFHD":
             raise TypeError(f"unsupported backbone {self.kind}")
+        self._plans = {}
+        self._twin = None
 
     def dispatch_name(self):
-        return "eager per-layer launches"
+        if self.eager:
+            return "eager per-layer launches (5 host syncs per step)"
+        return ("one captured HIP graph per step" if self.dispatch == "graph" else
+                "sync-free queued launches") + " (device-resident row counts, one count check per step)"
 
     def eager_twin(self):
-        """The same plan with per-layer launches from the host (each C-ABI call can then be bracketed by events)."""
-        return self
+        """The same compiled steps on per-layer launches from the host (each C-ABI call can then be bracketed by
+        events; also the reference the captured plan is tested against)."""
+        if self.eager:
+            return self
+        if self._twin is None:
+            t = object.__new__(FusedBackbone)
+            t.__dict__.update(self.__dict__)
+            t.eager, t._plans, t._twin = True, {}, None
+            self._twin = t
+        return self._twin
 
+    # ---- captured path ------------------------------------------------------------------------------------
+    @staticmethod
+    def _cap(n, headroom):
+        return max(1024, int(-(-int(n * headroom) // 1024) * 1024))
+
+    def _probe(self, gen, frames, grid):
+        """Eager geometry pass over these clouds -> (voxel count, [output rows of every strided conv in plan order])."""
+        from .voxel import voxelize_batch
+        mean, coords, _ = voxelize_batch(gen, frames)
+        sparse_shape = [int(v) for v in (np.array(grid[::-1]) + [1, 0, 0])]
+        st = _State(mean, coords.int().contiguous(), sparse_shape, len(frames), {})
+        # _run visits strided convs in order and caches each under a ("conv", ...) key: dict order = plan order
+        geo = _run(self.middle, st, geom_only=True)
+        if self.kind == "MultiViewBackbone":
+            _run(self.bev, geo, geom_only=True)
+            _run(self.rv, geo, geom_only=True)
+        need = [rb.n_out for key, rb in st.cache.items() if key[0] == "conv"]
+        return int(coords.shape[0]), need
+
+    def _build_plan(self, gen, frames, grid, old=None):
+        """Capacities from an eager geometry pass over these clouds (exact counts, with its host syncs: paid once
+        per plan), never below those of the plan being replaced."""
+        need_rows, need = self._probe(gen, frames, grid)
+        h = self.HEADROOM
+        points = sum(int(f.shape[0]) for f in frames)
+        cap_points, cap_rows, caps = self._cap(points, h), self._cap(need_rows, h), [self._cap(n, h) for n in need]
+        if old is not None:
+            cap_points, cap_rows = max(cap_points, old.cap_points), max(cap_rows, old.cap_rows)
+            caps = [max(a, b) for a, b in zip(caps, old.caps)]
+        plan = FramePlan(self, gen, len(frames), grid, cap_points, cap_rows, caps, frames[0].device)
+        plan.stage(frames)
+        return plan.capture() if self.dispatch == "graph" else plan
+
+    def forward_frames(self, gen, frames, grid):
+        """Voxelize + mean VFE + backbone for a list of CUDA clouds f32[N_i, 5]. The captured path returns tensors
+        OWNED BY THE PLAN: they are overwritten by the next call with the same number of frames."""
+        if self.eager:
+            from .voxel import voxelize_batch
+            mean, coords, _ = voxelize_batch(gen, frames)
+            return self(mean, coords, len(frames), grid)
+        if any(f.shape[0] > gen._max_voxels for f in frames) or not 1 <= len(frames) <= 64:
+            return self.eager_twin().forward_frames(gen, frames, grid)     # max_voxels truncation: per-frame calls
+        key = (id(gen), len(frames), tuple(grid))
+        plan = self._plans.get(key)
+        points = sum(int(f.shape[0]) for f in frames)
+        if plan is None or points > plan.cap_points:
+            plan = self._plans[key] = self._build_plan(gen, frames, grid, plan)
+        stream = torch.cuda.current_stream(plan.dev)
+        for attempt in range(2):
+            plan.stage(frames)
+            plan.replay()
+            stream.synchronize()
+            if plan.overflow() is None:
+                return plan.out
+            # some count exceeded its capacity (rows were dropped, so the counts after it are not reliable either):
+            # size a new plan from an exact geometry pass over THIS input and run again
+            plan = self._plans[key] = self._build_plan(gen, frames, grid, plan)
+        raise ops.L.VxError("FramePlan: a plan sized from this very input overflowed")
+
+    # ---- per-layer path ------------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, voxel_features, coors, batch_size, input_shape, out=None):
         sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
