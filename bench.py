@@ -54,6 +54,8 @@ def parse(argv=None):
                     help="sub-batches of a step on alternating HIP streams (vista_amd.engine.FramePipeline)")
     ap.add_argument("--torch-bn", action="store_true",
                     help="--mode train: stock torch BatchNorm1d/ReLU/add kernels instead of the fused libvx ones (A/B)")
+    ap.add_argument("--flat-allreduce", action="store_true",
+                    help="--mode train: one flat gradient all-reduce after backward instead of overlapped buckets (A/B)")
     ap.add_argument("--eager", action="store_true",
                     help="inference: per-layer launches from the host (no captured plan), the round-1 path (A/B)")
     ap.add_argument("--dispatch", default=None, choices=["queued", "graph"],

@@ -98,3 +98,60 @@ def test_sync_batchnorm_sum_exchange_gives_global_statistics():
     mean, var = s[:16] / n, s[16:32] / n - (s[:16] / n) ** 2
     assert torch.allclose(mean, x.mean(0), rtol=1e-12, atol=1e-12)
     assert torch.allclose(var, x.var(0, unbiased=False), rtol=1e-10, atol=1e-12)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vista_amd.train import GradBuckets, allreduce_grads_flat
+
+    def make():
+        torch.manual_seed(0)
+        return torch.nn.ModuleDict(dict(a=torch.nn.Linear(6, 8), b=torch.nn.Linear(8, 5), c=torch.nn.Linear(5, 3),
+                                        unused=torch.nn.Linear(4, 4)))
+
+    def loss_of(net, x):
+        y = net["c"](torch.relu(net["b"](torch.relu(net["a"](x)))))
+        if rank == 1:                       # only rank 1 touches `unused`: on rank 0 its gradient is None
+            y = y + net["unused"](x[:, :4]).sum() * 0.1
+        return (y ** 2).sum()
+
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(5, 6, generator=g)
+    flat_net, bucket_net = make(), make()
+    loss_of(flat_net, x).backward()
+    assert (flat_net["unused"].weight.grad is None) == (rank == 0)
+    nbytes = allreduce_grads_flat(list(flat_net.parameters()), dist, world)
+    gb = GradBuckets(bucket_net.named_parameters(), 3, dist, world)
+    for _ in range(2):                      # twice: the second step starts from zero() with the views still attached
+        gb.zero()
+        loss_of(bucket_net, x).backward()
+        assert gb.finish() == nbytes
+    flat = torch.cat([p.grad.reshape(-1) for p in flat_net.parameters()])
+    buck = torch.cat([p.grad.reshape(-1) for p in bucket_net.parameters()])
+    q.put((rank, flat.numpy().tobytes(), buck.numpy().tobytes(), list(gb.log), len(gb.bounds)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_equals_flat_exchange_bitwise_with_a_missing_gradient():
+    """GradBuckets (gradients as views of one flat buffer, buckets reduced as they complete) against the single flat
+    all-reduce: identical bits on both ranks, although rank 0 has no gradient for one parameter."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, flat, buck, log, nb in res:
+        assert flat == buck and len(flat) > 0
+        assert nb >= 2 and [b for b, _ in log] == list(range(nb))      # same order of collectives on every rank
+    assert res[0][1] == res[1][1]
+    # rank 0 never saw a gradient for `unused`: its bucket cannot complete from hooks there and is sent by finish()
+    assert any(why == "finish" for _, why in res[0][3]) and all(why == "hook" for _, why in res[1][3])

@@ -129,20 +129,25 @@ def _frames(dev, seeds, sweeps):
     return [torch.from_numpy(lidar_cloud(seed=s, sweeps=sweeps)).to(dev) for s in seeds]
 
 
+@pytest.mark.parametrize("dispatch", ["queued", "graph"])
 @pytest.mark.parametrize("kind,geometry,dtype", [("SpMiddleResNetFHD", "FHD", torch.float32),
                                                  ("SpMiddleResNetFHD", "FHD", torch.bfloat16),
                                                  ("MultiViewBackbone", "VISTA", torch.float32)])
-def test_sync_free_plan_equals_eager_path_bitwise(kind, geometry, dtype, dev):
-    """Full-size frames: the sync-free plan (queued launches) against per-layer launches, then the same plan on
-    DIFFERENT frames (other counts, same capacities) and a batch-1 plan next to the batch-2 one."""
+def test_sync_free_plan_equals_eager_path_bitwise(kind, geometry, dtype, dispatch, dev):
+    """Full-size frames: the sync-free plan (queued launches / one captured HIP graph) against per-layer launches,
+    then the same plan on DIFFERENT frames (other counts, same capacities: for the graph this is a replay of nodes
+    recorded on other data) and a batch-1 plan next to the batch-2 one."""
     from vista_amd.synth import GEOMETRIES, grid_size
     from vista_amd.voxel import VoxelGenerator
     rg, vs, T, mv = GEOMETRIES[geometry]
     gen = VoxelGenerator(vs, rg, T, mv)
     grid = grid_size(rg, vs).tolist()
-    eng = _engine(kind, dev, dtype)
+    eng = _engine(kind, dev, dtype, dispatch)
     eager = eng.eager_twin()
     assert eager.eager and not eng.eager
+    builds = []
+    real = type(eng)._build_plan
+    eng._build_plan = lambda *a, **k: (builds.append(1), real(eng, *a, **k))[1]
     for seeds in ([0, 1], [7, 5], [3]):
         fr = _frames(dev, seeds, 10)
         got = eng.forward_frames(gen, fr, grid)
@@ -151,7 +156,7 @@ def test_sync_free_plan_equals_eager_path_bitwise(kind, geometry, dtype, dev):
         for g, r in zip(got, ref):
             assert g.shape == r.shape and g.dtype == r.dtype
             assert torch.equal(_bits(g), _bits(r))
-    assert len(eng._plans) == 2          # batch 2 (captured once, replayed for the second pair of frames) and batch 1
+    assert len(eng._plans) == 2 and len(builds) == 2   # batch 2 (built once, re-used for the second pair) and batch 1
 
 
 def test_plan_grows_when_a_count_exceeds_its_capacity(dev, monkeypatch):

@@ -82,6 +82,9 @@ __device__ __forceinline__ int vx_hash_find(const VxSlot* t, long long mask, lon
 }
 #endif
 
+// stream-ordered byte fill by a kernel (what hipMemsetAsync does, but safe under HIP graph capture: see vx_scan.hip)
+int32_t vx_fill_async(void* d_ptr, int value, size_t bytes, hipStream_t stream);
+
 // exclusive scan of int32 (device), total written to d_total (int64, optional)
 size_t vx_scan_workspace_bytes(int64_t n);
 int32_t vx_scan_exclusive_i32(const int32_t* d_in, int32_t* d_out, int64_t n, int64_t* d_total,

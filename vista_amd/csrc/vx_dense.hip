@@ -46,7 +46,7 @@ static int32_t to_dense_impl(const void* d_feat, const int32_t* d_coords, int64_
   const size_t esz = dtype == VX_F32 ? 4 : 2;
   VX_REQUIRE(shape && d_dense && batch >= 1 && c >= 1 && c <= 4096 && n >= 0, "to_dense: bad arguments");
   const size_t total = (size_t)batch * c * shape[0] * shape[1] * shape[2];
-  VX_HIP(hipMemsetAsync(d_dense, 0, total * esz, stream));
+  if (int32_t rc_ = vx_fill_async(d_dense, 0, total * esz, stream)) return rc_;
   if (n == 0) return VX_OK;
   VX_REQUIRE(d_feat && d_coords, "to_dense: null pointer");
   const size_t lds = (size_t)kRows * (c + 1) * esz;

@@ -434,7 +434,7 @@ static int32_t subm_impl(const int32_t* d_coords, int64_t n, const int64_t* d_n,
   if (rc) return rc;
   const int half = g.kvol / 2;                       // odd kvol: offsets 0..half-1 mirror half+1..kvol-1
   if (half > 0)
-    VX_HIP(hipMemsetAsync(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream));
+    if (int32_t rc_ = vx_fill_async(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream)) return rc_;
   dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)(half + 1));
   subm_nbr<<<grid, kThreads, 0, stream>>>(d_coords, n, (const long long*)d_n, g, w.table, w.cap - 1, d_nbr,
                                           nbr_ld);
@@ -458,7 +458,7 @@ extern "C" int32_t vx_rulebook_subm_dn(const int32_t* d_coords, const int64_t* d
 // phase 1 of the strided conv: occupancy of the output grid -> sorted rank {bits, base} per 32 cells, total -> d_total
 static int32_t conv_count_impl(const int32_t* d_coords, int64_t n_in, const int64_t* d_n_in, const ConvGeom& g,
                                const RbWs& w, int64_t* d_total, long long* d_err, hipStream_t stream) {
-  VX_HIP(hipMemsetAsync(w.bytemap, 0, 32 * (size_t)w.nwords, stream));
+  if (int32_t rc_ = vx_fill_async(w.bytemap, 0, 32 * (size_t)w.nwords, stream)) return rc_;
   conv_mark<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(d_coords, n_in, (const long long*)d_n_in, g,
                                                                         w.bytemap, d_err);
   VX_LAUNCH_CHECK();
@@ -480,7 +480,7 @@ static int32_t conv_emit_impl(const int32_t* d_coords, int64_t n_in, const int64
   uint2* rank = d_rank ? (uint2*)d_rank : (uint2*)w.rank_tmp;
   rank_interleave<<<gw, kThreads, 0, stream>>>(w.bitmap, w.base, w.nwords, rank);
   VX_LAUNCH_CHECK();
-  VX_HIP(hipMemsetAsync(d_nbr, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_ld, stream));
+  if (int32_t rc_ = vx_fill_async(d_nbr, 0xff, 4 * (size_t)g.kvol * (size_t)nbr_ld, stream)) return rc_;
   conv_pairs_from_inputs<<<(unsigned)vx_cdiv(n_in, kThreads), kThreads, 0, stream>>>(
       d_coords, n_in, (const long long*)d_n_in, g, rank, d_nbr, nbr_ld, cap_out, d_nbr_t, nbr_t_ld);
   VX_LAUNCH_CHECK();
@@ -508,7 +508,7 @@ extern "C" int32_t vx_rulebook_conv_count(const int32_t* d_coords, int64_t n_in,
     vx_set_error("rulebook_conv_count: workspace %zu < %zu", ws_bytes, w.bytes);
     return VX_ERR_WORKSPACE;
   }
-  VX_HIP(hipMemsetAsync(w.total, 0, 16, stream));          // {output rows, error word}
+  if (int32_t rc_ = vx_fill_async(w.total, 0, 16, stream)) return rc_;          // {output rows, error word}
   int32_t rc = conv_count_impl(d_coords, n_in, nullptr, g, w, (int64_t*)w.total, w.total + 1, stream);
   if (rc) return rc;
   int64_t h[2] = {0, 0};
@@ -590,7 +590,7 @@ static int32_t subm_ranked_impl(const int32_t* d_coords, int64_t n, const int64_
   VX_REQUIRE(d_coords && d_nbr && nbr_ld >= n, "rulebook_subm_ranked: bad table pointer / stride");
   const int half = g.kvol / 2;
   if (half > 0)
-    VX_HIP(hipMemsetAsync(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream));
+    if (int32_t rc_ = vx_fill_async(d_nbr + (size_t)(half + 1) * nbr_ld, 0xff, sizeof(int32_t) * (size_t)half * nbr_ld, stream)) return rc_;
   dim3 grid((unsigned)vx_cdiv(n, kThreads), (unsigned)(half + 1));
   subm_nbr_ranked<<<grid, kThreads, 0, stream>>>(d_coords, n, (const long long*)d_n, g, (const uint2*)d_rank,
                                                  d_nbr, nbr_ld);
@@ -645,7 +645,7 @@ extern "C" int32_t vx_nbr_to_pairs(const int32_t* d_nbr, int64_t nbr_ld, int32_t
   hipStream_t stream = (hipStream_t)stream_;
   VX_REQUIRE(kvol >= 1 && kvol <= 125 && n_out >= 0 && d_pair_num, "nbr_to_pairs: bad arguments");
   if (n_out == 0) {
-    VX_HIP(hipMemsetAsync(d_pair_num, 0, 4 * (size_t)kvol, stream));
+    if (int32_t rc_ = vx_fill_async(d_pair_num, 0, 4 * (size_t)kvol, stream)) return rc_;
     return VX_OK;
   }
   VX_REQUIRE(d_nbr && d_pairs && d_ws && nbr_ld >= n_out, "nbr_to_pairs: null pointer / stride");
@@ -658,7 +658,7 @@ extern "C" int32_t vx_nbr_to_pairs(const int32_t* d_nbr, int64_t nbr_ld, int32_t
   int* wcnt = (int*)d_ws;
   int* woff = (int*)((char*)d_ws + a);
   void* sws = (char*)d_ws + 2 * a;
-  VX_HIP(hipMemsetAsync(d_pairs, 0xff, 4 * (size_t)kvol * 2 * (size_t)n_out, stream));
+  if (int32_t rc_ = vx_fill_async(d_pairs, 0xff, 4 * (size_t)kvol * 2 * (size_t)n_out, stream)) return rc_;
   dim3 grid((unsigned)vx_cdiv(n_out, kThreads), (unsigned)kvol);
   pairs_count<<<grid, kThreads, 0, stream>>>(d_nbr, nbr_ld, n_out, nw, wcnt);
   VX_LAUNCH_CHECK();

@@ -107,6 +107,37 @@ __global__ __launch_bounds__(kThreads) void scan_apply_kernel(const int* __restr
 }
 }  // namespace
 
+// ---- fill kernel used instead of hipMemsetAsync ---------------------------------------------------------------
+// hipMemsetAsync nodes captured in a HIP graph ran out of order on every replay after the first (ROCm 7.2, gfx950;
+// tools/graph_memset_probe.py: a kernel - memset - kernel chain left 19-100 % of the bytes wrong from the second replay
+// on), which made the captured step fault on new inputs. A plain kernel node keeps its place in the chain, so every
+// fill on a path that may be captured is this kernel: 16-byte vector stores over the aligned body, bytes at the ends.
+namespace {
+__global__ __launch_bounds__(256) void fill_kernel(unsigned char* __restrict__ p, unsigned value, size_t head,
+                                                   size_t quads, size_t tail) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned w = value * 0x01010101u;
+  uint4* body = reinterpret_cast<uint4*>(p + head);
+  for (size_t q = i; q < quads; q += (size_t)gridDim.x * 256) body[q] = make_uint4(w, w, w, w);
+  if (i < head) p[i] = (unsigned char)value;
+  if (i < tail) p[head + 16 * quads + i] = (unsigned char)value;
+}
+}  // namespace
+
+int32_t vx_fill_async(void* d_ptr, int value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return VX_OK;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(d_ptr);
+  size_t head = (16 - (a & 15)) & 15;
+  if (head > bytes) head = bytes;
+  const size_t quads = (bytes - head) / 16, tail = bytes - head - 16 * quads;
+  size_t blocks = (quads + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 16384) blocks = 16384;          // grid-stride beyond that: 16384 x 256 lanes x 16 B = 64 MiB per sweep
+  fill_kernel<<<(unsigned)blocks, 256, 0, stream>>>((unsigned char*)d_ptr, (unsigned)value & 0xffu, head, quads, tail);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
 size_t vx_scan_workspace_bytes(int64_t n) {
   size_t bytes = 0;
   int64_t m = vx_cdiv(n > 0 ? n : 1, kTile);
@@ -121,7 +152,7 @@ size_t vx_scan_workspace_bytes(int64_t n) {
 int32_t vx_scan_exclusive_i32(const int32_t* d_in, int32_t* d_out, int64_t n, int64_t* d_total,
                               void* d_ws, size_t ws_bytes, hipStream_t stream) {
   if (n <= 0) {
-    if (d_total) VX_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), stream));
+    if (d_total) return vx_fill_async(d_total, 0, sizeof(int64_t), stream);
     return VX_OK;
   }
   if (ws_bytes < vx_scan_workspace_bytes(n)) {
@@ -144,5 +175,32 @@ int32_t vx_scan_exclusive_i32(const int32_t* d_in, int32_t* d_out, int64_t n, in
   scan_apply_kernel<<<(unsigned)nb, kThreads, 0, stream>>>(d_in, d_out, sums, n,
                                                            (long long*)d_total);
   VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+// ---- diagnostic (tools/graph_stale_probe.py): what does a kernel see of a device word that a copy or an earlier
+// kernel rewrote just before it -- through a plain (scalar-cache) load, a plain vector load and an agent-scope load?
+__global__ void vx_echo_kernel(const long long* __restrict__ src, long long* __restrict__ out_scalar,
+                               long long* __restrict__ out_vector, long long* __restrict__ out_agent) {
+  const long long s = *src;                                   // uniform address: s_load through the scalar cache
+  const long long* vp = src + (threadIdx.x >> 10);            // same address, lane-dependent form: vector load
+  const long long v = *vp;
+  const long long a = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    out_scalar[blockIdx.x] = s;
+    out_vector[blockIdx.x] = v;
+    out_agent[blockIdx.x] = a;
+  }
+}
+extern "C" int32_t vx_debug_echo(const int64_t* d_src, int64_t* d_out_scalar, int64_t* d_out_vector,
+                                 int64_t* d_out_agent, int32_t blocks, void* stream) {
+  vx_echo_kernel<<<blocks, 64, 0, (hipStream_t)stream>>>((const long long*)d_src, (long long*)d_out_scalar,
+                                                         (long long*)d_out_vector, (long long*)d_out_agent);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
+extern "C" int32_t vx_debug_memset(void* d_ptr, int32_t value, size_t bytes, void* stream) {
+  VX_HIP(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
   return VX_OK;
 }

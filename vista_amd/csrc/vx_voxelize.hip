@@ -300,7 +300,7 @@ static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const
   VX_REQUIRE(cells < (1ll << 40), "voxelize: grid too large");
   const size_t n_counts = n_frames > 1 ? (size_t)n_frames + 1 : 1;
   if (n == 0) {
-    VX_HIP(hipMemsetAsync(d_num_voxels, 0, sizeof(int64_t) * n_counts, stream));
+    if (int32_t rc_ = vx_fill_async(d_num_voxels, 0, sizeof(int64_t) * n_counts, stream)) return rc_;
   } else {
     const unsigned gp = (unsigned)vx_cdiv(n, kThreads);
     vox_init_table<<<(unsigned)vx_cdiv(w.cap, kThreads), kThreads, 0, stream>>>(w.table, w.cap);
@@ -314,8 +314,8 @@ static int32_t voxelize_impl(const float* d_points, int64_t n, int32_t nf, const
     if (rc) return rc;
     const bool lists = d_voxels || d_mean;
     if (lists) {
-      VX_HIP(hipMemsetAsync(w.cntv, 0, 4 * (size_t)n, stream));
-      VX_HIP(hipMemsetAsync(w.fill, 0, 4 * (size_t)n, stream));
+      if (int32_t rc_ = vx_fill_async(w.cntv, 0, 4 * (size_t)n, stream)) return rc_;
+      if (int32_t rc_ = vx_fill_async(w.fill, 0, 4 * (size_t)n, stream)) return rc_;
     }
     // d_num_voxels[0] = total; [1 .. n_frames] = per-frame counts (batched call only)
     vox_assign<<<gp, kThreads, 0, stream>>>(w.table, w.slot_of, w.flag, w.pos, n, g, max_points,

@@ -177,6 +177,7 @@ class FramePlan:
         self.h_offsets = torch.zeros((nf + 1,), dtype=torch.int64).pin_memory()
         self.graph = None
         self.out = None
+        self.limit = None          # diagnostic (tools/graph_probe.py): stop after this many steps of the middle stack
 
     def _forward(self):
         from . import ops_dn
@@ -189,6 +190,9 @@ class FramePlan:
         st = _State(mean, coords, sparse_shape, self.n_frames, cache)
         args = (self.caps, self.counts, self.slot, self.counts[0:1])
         from . import ops_dn as od
+        if self.limit is not None:
+            mid = _run_dn(e.middle[:self.limit], st, *args)
+            return mid.feat, mid.idx
         mid = _run_dn(e.middle, st, *args)
         if e.kind == "SpMiddleResNetFHD":
             d = od.to_dense_dn(mid.feat, mid.idx, mid.n, mid.batch, mid.shape)
@@ -263,7 +267,7 @@ class FusedBackbone:
         self.dtype = dtype
         self.eager = bool(eager)
         # how forward_frames issues a step: "queued" (sync-free launches on the stream) or "graph" (captured HIP graph)
-        self.dispatch = dispatch or os.environ.get("VX_DISPATCH", "queued")
+        self.dispatch = dispatch or os.environ.get("VX_DISPATCH", "graph")
         if self.dispatch not in ("queued", "graph"):
             raise ValueError("dispatch must be 'queued' or 'graph'")
         self.mode = getattr(module, "mode", "bev")

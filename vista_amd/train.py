@@ -9,7 +9,8 @@
 One process per GPU; the only collective on the data path is the gradient all-reduce (RCCL over xGMI
 when the backend is "nccl"; gloo in the CPU tests). The backbone holds ~2.7 M fp32 parameters
 (10.8 MB): on point-to-point xGMI a ring all-reduce of that size is latency-bound, so the whole
-gradient goes out as ONE flat bucket right after backward instead of DDP's per-bucket hooks.
+gradient lives in ONE flat buffer (GradBuckets): a handful of contiguous slices, deepest stage first, are
+reduced as soon as their gradients are complete, overlapping the remaining dgrad/wgrad kernels.
 """
 import time
 
@@ -26,27 +27,137 @@ def shard_frames(n_frames, rank, world):
     return idx[rank::world][:per]
 
 
+def _all_reduce_sum(t, dist, async_op=False):
+    """Sum `t` over ranks in place. RCCL ("nccl") reduces device memory directly and can run asynchronously on its
+    own stream; CPU rehearsal backends (gloo) stage device tensors through host memory."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        host = t.cpu()
+        dist.all_reduce(host)
+        t.copy_(host)
+        return None
+    return dist.all_reduce(t, async_op=async_op)
+
+
 def allreduce_grads_flat(params, dist=None, world=1):
-    """Average gradients over ranks through one flat fp32 bucket. Returns the bucket size in bytes."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    """Average gradients over ranks through one flat fp32 bucket (det3d/core/utils/dist_utils.py:7-41). The bucket
+    covers EVERY parameter in the given order -- a parameter without a gradient on this rank contributes zeros and
+    receives the average -- so all ranks always reduce the same number of elements. Returns the bucket size in bytes."""
+    params = list(params)
+    if not params:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    ref = next((p.grad for p in params if p.grad is not None), params[0])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p, dtype=ref.dtype)).reshape(-1)
+                      for p in params])
     if dist is not None and world > 1:
-        if flat.is_cuda and dist.get_backend() != "nccl":
-            # CPU rehearsal backends (gloo) stage through host memory; RCCL reduces in place on the GPU
-            host = flat.cpu()
-            dist.all_reduce(host)
-            flat.copy_(host)
-        else:
-            dist.all_reduce(flat)
+        _all_reduce_sum(flat, dist)
         flat.div_(world)
         off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+        for p in params:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
             off += n
     return flat.numel() * flat.element_size()
+
+
+class GradBuckets:
+    """The gradient exchange of the data-parallel step (DDP's job at det3d/torchie/apis/train.py:302-308).
+
+    ONE flat fp32 buffer holds every gradient: each parameter's .grad is a view into it (no concatenation before and
+    no copy-back after the all-reduce, and zeroing is one fill). The buffer is laid out in BACKWARD order -- the
+    deepest stage first -- and cut into `n_buckets` contiguous slices. A post-accumulate hook counts the gradients
+    that have arrived; when a bucket is complete its all-reduce is issued at once (asynchronously on RCCL's stream
+    under the "nccl" backend), so the exchange of the deep stages overlaps the dgrad/wgrad kernels of the shallower
+    ones. finish() issues whatever did not fire (parameters that got no gradient this step still take part, as
+    zeros, so every rank reduces the same slices), waits, and divides by the world size.
+    Bucketed and single-bucket exchanges give identical sums element by element."""
+
+    def __init__(self, named_params, n_buckets=4, dist=None, world=1):
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        if not named:
+            raise ValueError("no trainable parameters")
+        self.dist, self.world = dist, int(world)
+        order = named[::-1]                                   # backward order: last layer's gradients arrive first
+        dev, dtype = order[0][1].device, order[0][1].dtype
+        total = sum(p.numel() for _, p in order)
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self.nbytes = total * self.flat.element_size()
+        # contiguous buckets of about total / n_buckets elements
+        n_buckets = max(1, min(int(n_buckets), len(order)))
+        self.bounds, self.members = [], []
+        off = start = 0
+        target = total / n_buckets
+        cur = []
+        for i, (name, p) in enumerate(order):
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+            cur.append(name)
+            if (off - start >= target and len(self.bounds) < n_buckets - 1) or i == len(order) - 1:
+                self.bounds.append((start, off))
+                self.members.append(cur)
+                start, cur = off, []
+        self.bucket_of = {}
+        for b, names in enumerate(self.members):
+            for name in names:
+                self.bucket_of[name] = b
+        self.params = dict(order)
+        self.arrived = [0] * len(self.bounds)
+        self.fired = [False] * len(self.bounds)
+        self.next = 0                                         # next bucket to send
+        self.works = []
+        self.log = []                                         # (bucket, "hook" | "finish") in firing order
+        for name, p in order:
+            p.register_post_accumulate_grad_hook(self._make_hook(name, p))
+
+    def _make_hook(self, name, p):
+        b = self.bucket_of[name]
+        lo = sum(self.params[n].numel() for n in self.members[b][:self.members[b].index(name)]) + self.bounds[b][0]
+
+        def hook(param):
+            g = param.grad
+            if g is None or g.data_ptr() != self.flat.data_ptr() + lo * self.flat.element_size():
+                # something replaced the view (e.g. zero_grad(set_to_none=True)): copy in and re-attach
+                if g is not None:
+                    self.flat[lo:lo + param.numel()].copy_(g.reshape(-1))
+                param.grad = self.flat[lo:lo + param.numel()].view_as(param)
+            self.arrived[b] += 1
+            # buckets go out strictly in index order, so every rank issues the same sequence of collectives even
+            # when some rank never completes a bucket from its hooks (a parameter without a gradient there)
+            while self.next < len(self.bounds) and self.arrived[self.next] == len(self.members[self.next]):
+                self._fire(self.next, "hook")
+        return hook
+
+    def _fire(self, b, why):
+        assert b == self.next
+        self.next += 1
+        self.fired[b] = True
+        self.log.append((b, why))
+        if self.dist is not None and self.world > 1:
+            lo, hi = self.bounds[b]
+            w = _all_reduce_sum(self.flat[lo:hi], self.dist, async_op=True)
+            if w is not None:
+                self.works.append(w)
+
+    def zero(self):
+        """Start of a step (instead of optimizer.zero_grad): one fill; the .grad views stay attached."""
+        self.flat.zero_()
+        self.arrived = [0] * len(self.bounds)
+        self.fired = [False] * len(self.bounds)
+        self.works, self.log, self.next = [], [], 0
+
+    def finish(self):
+        """After backward: reduce the buckets that did not fire, wait for all of them, average."""
+        while self.next < len(self.bounds):
+            self._fire(self.next, "finish")
+        for w in self.works:
+            w.wait()
+        if self.dist is not None and self.world > 1:
+            self.flat.div_(self.world)
+        return self.nbytes
 
 
 def wrap_sync_bn(module, world, dist=None):
@@ -57,13 +168,21 @@ def wrap_sync_bn(module, world, dist=None):
     return module
 
 
-def train_step(net, opt, mean, coords, batch, grid, dist=None, world=1):
-    """fwd + loss = mean(dense_out^2) + bwd (libvx dgrad/wgrad) + gradient all-reduce + optimizer step."""
-    opt.zero_grad(set_to_none=True)
+def train_step(net, opt, mean, coords, batch, grid, dist=None, world=1, buckets=None):
+    """fwd + loss = mean(dense_out^2) + bwd (libvx dgrad/wgrad) + gradient all-reduce + optimizer step.
+    With `buckets` (a GradBuckets over net's parameters) the exchange overlaps backward; without, one flat
+    all-reduce after backward (dist_utils.py:7-41)."""
+    if buckets is not None:
+        buckets.zero()
+    else:
+        opt.zero_grad(set_to_none=True)
     out = net(mean, coords, batch, grid)
     loss = (out * out).mean()
     loss.backward()
-    allreduce_grads_flat(list(net.parameters()), dist, world)
+    if buckets is not None:
+        buckets.finish()
+    else:
+        allreduce_grads_flat(list(net.parameters()), dist, world)
     opt.step()
     return loss.detach()
 
@@ -84,11 +203,12 @@ def bench_train(a, dev, rank, world, dist):
         from .fused_bn import fuse_for_training      # libvx BatchNorm(+add+ReLU) kernels; global statistics when world > 1
         net = fuse_for_training(net, sync=world > 1)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    buckets = None if getattr(a, "flat_allreduce", False) else GradBuckets(net.named_parameters(), 4, dist, world)
     frames = [torch.from_numpy(lidar_cloud(seed=rank * a.batch + b, sweeps=10)).to(dev) for b in range(a.batch)]
 
     def step():
         mean, coords, _ = voxelize_batch(gen, frames)
-        return train_step(net, opt, mean, coords, len(frames), grid, dist, world)
+        return train_step(net, opt, mean, coords, len(frames), grid, dist, world, buckets)
 
     def barrier():
         if dist is not None:
@@ -120,7 +240,10 @@ def bench_train(a, dev, rank, world, dist):
         "config": {"workload": f"{a.geometry} 10-sweep synthetic frames, batch {a.batch}/GPU, DP training step "
                                "(BASELINE.json configs[4]), loss = mean(out^2), SyncBN when >1 GPU, "
                                + ("torch BatchNorm/ReLU kernels" if getattr(a, "torch_bn", False) else
-                                  "fused libvx BatchNorm+add+ReLU kernels"),
+                                  "fused libvx BatchNorm+add+ReLU kernels")
+                               + (", one flat gradient all-reduce after backward" if buckets is None else
+                                  f", gradients in one flat buffer exchanged as {len(buckets.bounds)} buckets (deep stages "
+                                  "first) overlapped with backward"),
                    "frames_per_gpu": a.batch, "parallelism": f"dp{world}", "grad_bucket_bytes": 4 * nparam},
         "final_loss": float(loss.item()),
     }
