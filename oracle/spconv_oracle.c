@@ -211,94 +211,110 @@ void orc_nbr_to_pairs(const int32_t *nbr, int K, int64_t n_out, int32_t *pairs, 
   }
 }
 
-/* weights arrive KRSC [Cout][K][Cin]; repack to [K][Cin][Cout] for a unit-stride inner loop */
-static float *repack_kio(const float *w, int K, int cin, int cout) {
-  float *r = (float *)malloc(sizeof(float) * (size_t)K * cin * cout);
-  for (int co = 0; co < cout; ++co)
-    for (int k = 0; k < K; ++k)
-      for (int ci = 0; ci < cin; ++ci)
-        r[((size_t)k * cin + ci) * cout + co] = w[((size_t)co * K + k) * cin + ci];
-  return r;
-}
-
-/* forward: out[o] = bias + sum_k sum_ci in[nbr[k][o]][ci] * W[co][k][ci], fp32, k then ci order.
- * Equivalent to per-offset gather-GEMM-scatter; written output-stationary so threads never
- * share an output row (deterministic for any thread count). */
-int orc_conv_fwd(const float *in, int64_t n_in, int cin, const float *w, int K, int cout,
-                 const int32_t *nbr, int64_t n_out, const float *bias, float *out) {
-  (void)n_in;
-  float *wk = repack_kio(w, K, cin, cout);
-  if (!wk) return -1;
-#pragma omp parallel for schedule(dynamic, 64)
-  for (int64_t o = 0; o < n_out; ++o) {
-    float *dst = out + o * cout;
-    for (int co = 0; co < cout; ++co) dst[co] = bias ? bias[co] : 0.0f;
-    for (int k = 0; k < K; ++k) {
-      int32_t i = nbr[(int64_t)k * n_out + o];
-      if (i < 0) continue;
-      const float *src = in + (int64_t)i * cin;
-      const float *wp = wk + (size_t)k * cin * cout;
-      for (int ci = 0; ci < cin; ++ci) {
-        const float a = src[ci];
-        const float *wr = wp + (size_t)ci * cout;
-        for (int co = 0; co < cout; ++co) dst[co] += a * wr[co];
-      }
-    }
+/* The three arithmetic routines exist in two precisions: fp32 (the reference's own precision, the oracle proper)
+ * and fp64 (suffix _f64: the "truth" that tests use to tell the GPU's rounding error from the fp32 oracle's own). */
+#define ORC_DEFINE_CONV(REAL, SFX)                                                                        \
+  /* weights arrive KRSC [Cout][K][Cin]; repack to [K][Cin][Cout] for a unit-stride inner loop */         \
+  static REAL *repack_kio##SFX(const REAL *w, int K, int cin, int cout) {                                 \
+    REAL *r = (REAL *)malloc(sizeof(REAL) * (size_t)K * cin * cout);                                      \
+    for (int co = 0; co < cout; ++co)                                                                     \
+      for (int k = 0; k < K; ++k)                                                                         \
+        for (int ci = 0; ci < cin; ++ci)                                                                  \
+          r[((size_t)k * cin + ci) * cout + co] = w[((size_t)co * K + k) * cin + ci];                     \
+    return r;                                                                                             \
+  }                                                                                                       \
+  /* forward: out[o] = bias + sum_k sum_ci in[nbr[k][o]][ci] * W[co][k][ci], k then ci order.             \
+   * Equivalent to per-offset gather-GEMM-scatter; written output-stationary so threads never             \
+   * share an output row (deterministic for any thread count). */                                         \
+  int orc_conv_fwd##SFX(const REAL *in, int64_t n_in, int cin, const REAL *w, int K, int cout,            \
+                        const int32_t *nbr, int64_t n_out, const REAL *bias, REAL *out) {                 \
+    (void)n_in;                                                                                           \
+    REAL *wk = repack_kio##SFX(w, K, cin, cout);                                                          \
+    if (!wk) return -1;                                                                                   \
+    _Pragma("omp parallel for schedule(dynamic, 64)")                                                     \
+    for (int64_t o = 0; o < n_out; ++o) {                                                                 \
+      REAL *dst = out + o * cout;                                                                         \
+      for (int co = 0; co < cout; ++co) dst[co] = bias ? bias[co] : (REAL)0;                              \
+      for (int k = 0; k < K; ++k) {                                                                       \
+        int32_t i = nbr[(int64_t)k * n_out + o];                                                          \
+        if (i < 0) continue;                                                                              \
+        const REAL *src = in + (int64_t)i * cin;                                                          \
+        const REAL *wp = wk + (size_t)k * cin * cout;                                                     \
+        for (int ci = 0; ci < cin; ++ci) {                                                                \
+          const REAL a = src[ci];                                                                         \
+          const REAL *wr = wp + (size_t)ci * cout;                                                        \
+          for (int co = 0; co < cout; ++co) dst[co] += a * wr[co];                                        \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+    free(wk);                                                                                             \
+    return 0;                                                                                             \
+  }                                                                                                       \
+  /* dgrad: din[i] = sum over (k,o) with nbr[k][o]==i of W[:,k,:]^T dout[o]; accumulation order           \
+   * k ascending (each (i,k) has at most one o). The table is transposed first so that threads own        \
+   * input rows: same sums in the same order for any thread count. */                                     \
+  int orc_conv_dgrad##SFX(const REAL *dout, int64_t n_out, int cout, const REAL *w, int K, int cin,       \
+                          const int32_t *nbr, int64_t n_in, REAL *din) {                                  \
+    int32_t *tr = (int32_t *)malloc(sizeof(int32_t) * (size_t)K * (size_t)(n_in > 0 ? n_in : 1));         \
+    if (!tr) return -1;                                                                                   \
+    memset(tr, 0xff, sizeof(int32_t) * (size_t)K * (size_t)(n_in > 0 ? n_in : 1));                        \
+    for (int k = 0; k < K; ++k)                                                                           \
+      for (int64_t o = 0; o < n_out; ++o) {                                                               \
+        int32_t i = nbr[(int64_t)k * n_out + o];                                                          \
+        if (i >= 0) tr[(int64_t)k * n_in + i] = (int32_t)o;                                               \
+      }                                                                                                   \
+    _Pragma("omp parallel for schedule(dynamic, 64)")                                                     \
+    for (int64_t i = 0; i < n_in; ++i) {                                                                  \
+      REAL *dst = din + i * cin;                                                                          \
+      for (int ci = 0; ci < cin; ++ci) dst[ci] = (REAL)0;                                                 \
+      for (int k = 0; k < K; ++k) {                                                                       \
+        const int32_t o = tr[(int64_t)k * n_in + i];                                                      \
+        if (o < 0) continue;                                                                              \
+        const REAL *g = dout + (int64_t)o * cout;                                                         \
+        for (int co = 0; co < cout; ++co) {                                                               \
+          const REAL gv = g[co];                                                                          \
+          const REAL *wr = w + ((size_t)co * K + k) * cin;                                                \
+          for (int ci = 0; ci < cin; ++ci) dst[ci] += gv * wr[ci];                                        \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+    free(tr);                                                                                             \
+    return 0;                                                                                             \
+  }                                                                                                       \
+  /* wgrad: dW[co][k][ci] = sum_o dout[o][co] * in[nbr[k][o]][ci] (double accumulation, then REAL);       \
+   * dbias[co] = sum_o dout[o][co] if dbias != NULL. */                                                   \
+  int orc_conv_wgrad##SFX(const REAL *in, int64_t n_in, int cin, const REAL *dout, int64_t n_out,         \
+                          int cout, const int32_t *nbr, int K, REAL *dw, REAL *dbias) {                   \
+    (void)n_in;                                                                                           \
+    double *acc = (double *)calloc((size_t)cout * K * cin, sizeof(double));                               \
+    if (!acc) return -1;                                                                                  \
+    _Pragma("omp parallel for schedule(dynamic, 1)") /* a thread owns kernel offset k: ordered sums */    \
+    for (int k = 0; k < K; ++k)                                                                           \
+      for (int64_t o = 0; o < n_out; ++o) {                                                               \
+        int32_t i = nbr[(int64_t)k * n_out + o];                                                          \
+        if (i < 0) continue;                                                                              \
+        const REAL *src = in + (int64_t)i * cin;                                                          \
+        const REAL *g = dout + o * cout;                                                                  \
+        for (int co = 0; co < cout; ++co) {                                                               \
+          double *a = acc + ((size_t)co * K + k) * cin;                                                   \
+          const double gv = g[co];                                                                        \
+          for (int ci = 0; ci < cin; ++ci) a[ci] += gv * src[ci];                                         \
+        }                                                                                                 \
+      }                                                                                                   \
+    for (size_t t = 0; t < (size_t)cout * K * cin; ++t) dw[t] = (REAL)acc[t];                             \
+    free(acc);                                                                                            \
+    if (dbias) {                                                                                          \
+      for (int co = 0; co < cout; ++co) {                                                                 \
+        double s = 0;                                                                                     \
+        for (int64_t o = 0; o < n_out; ++o) s += dout[o * cout + co];                                     \
+        dbias[co] = (REAL)s;                                                                              \
+      }                                                                                                   \
+    }                                                                                                     \
+    return 0;                                                                                             \
   }
-  free(wk);
-  return 0;
-}
 
-/* dgrad: din[i] = sum over (k,o) with nbr[k][o]==i of W[:,k,:]^T dout[o]; accumulation order
- * k ascending (each (i,k) has at most one o). Sequential scatter (oracle; small sizes). */
-int orc_conv_dgrad(const float *dout, int64_t n_out, int cout, const float *w, int K, int cin,
-                   const int32_t *nbr, int64_t n_in, float *din) {
-  memset(din, 0, sizeof(float) * (size_t)n_in * cin);
-  for (int k = 0; k < K; ++k)
-    for (int64_t o = 0; o < n_out; ++o) {
-      int32_t i = nbr[(int64_t)k * n_out + o];
-      if (i < 0) continue;
-      float *dst = din + (int64_t)i * cin;
-      const float *g = dout + o * cout;
-      for (int co = 0; co < cout; ++co) {
-        const float gv = g[co];
-        const float *wr = w + ((size_t)co * K + k) * cin;
-        for (int ci = 0; ci < cin; ++ci) dst[ci] += gv * wr[ci];
-      }
-    }
-  return 0;
-}
-
-/* wgrad: dW[co][k][ci] = sum_o dout[o][co] * in[nbr[k][o]][ci] (double accumulation, then fp32);
- * dbias[co] = sum_o dout[o][co] if dbias != NULL. */
-int orc_conv_wgrad(const float *in, int64_t n_in, int cin, const float *dout, int64_t n_out,
-                   int cout, const int32_t *nbr, int K, float *dw, float *dbias) {
-  (void)n_in;
-  double *acc = (double *)calloc((size_t)cout * K * cin, sizeof(double));
-  if (!acc) return -1;
-  for (int k = 0; k < K; ++k)
-    for (int64_t o = 0; o < n_out; ++o) {
-      int32_t i = nbr[(int64_t)k * n_out + o];
-      if (i < 0) continue;
-      const float *src = in + (int64_t)i * cin;
-      const float *g = dout + o * cout;
-      for (int co = 0; co < cout; ++co) {
-        double *a = acc + ((size_t)co * K + k) * cin;
-        const double gv = g[co];
-        for (int ci = 0; ci < cin; ++ci) a[ci] += gv * src[ci];
-      }
-    }
-  for (size_t t = 0; t < (size_t)cout * K * cin; ++t) dw[t] = (float)acc[t];
-  free(acc);
-  if (dbias) {
-    for (int co = 0; co < cout; ++co) {
-      double s = 0;
-      for (int64_t o = 0; o < n_out; ++o) s += dout[o * cout + co];
-      dbias[co] = (float)s;
-    }
-  }
-  return 0;
-}
+ORC_DEFINE_CONV(float, )
+ORC_DEFINE_CONV(double, _f64)
 
 /* .dense(): zeros [B][C][D][H][W], out[b][c][z][y][x] = feat[row][c] */
 int orc_to_dense(const float *feat, const int32_t *coords, int64_t n, int c, int batch,

@@ -14,6 +14,7 @@ _lib = None
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
 
 
 def build(force=False):
@@ -109,43 +110,61 @@ def nbr_to_pairs(nbr):
     return pairs, num
 
 
-def conv_fwd(feat, weight, nbr, bias=None):
-    """feat f32[N_in,Cin], weight f32[Cout,kz,ky,kx,Cin] (KRSC), nbr int32[K,N_out] -> f32[N_out,Cout]."""
-    feat, weight, nbr = _f32(feat), _f32(weight), _i32(nbr)
+def _real(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _kind(dtype):
+    """(numpy dtype, ctypes pointer, symbol suffix) of a precision: float32 = the oracle proper, float64 = the
+    truth tests use to separate the GPU's rounding error from the fp32 oracle's own."""
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return np.float32, c_f32p, ""
+    if dt == np.float64:
+        return np.float64, c_f64p, "_f64"
+    raise ValueError(f"oracle precisions are float32 and float64, not {dt}")
+
+
+def conv_fwd(feat, weight, nbr, bias=None, dtype=np.float32):
+    """feat [N_in,Cin], weight [Cout,kz,ky,kx,Cin] (KRSC), nbr int32[K,N_out] -> [N_out,Cout] in `dtype`."""
+    dt, ptr, sfx = _kind(dtype)
+    feat, weight, nbr = _real(feat, dt), _real(weight, dt), _i32(nbr)
     cout, cin = weight.shape[0], weight.shape[-1]
     K, n_out = nbr.shape
     assert weight.size == cout * K * cin and feat.shape[1] == cin
-    out = np.zeros((n_out, cout), np.float32)
-    b = _f32(bias) if bias is not None else None
+    out = np.zeros((n_out, cout), dt)
+    b = _real(bias, dt) if bias is not None else None
     if n_out:
-        rc = lib().orc_conv_fwd(_p(feat, c_f32p), ctypes.c_int64(feat.shape[0]), ctypes.c_int(cin),
-                                _p(weight, c_f32p), ctypes.c_int(K), ctypes.c_int(cout),
-                                _p(nbr, c_i32p), ctypes.c_int64(n_out), _p(b, c_f32p), _p(out, c_f32p))
+        rc = getattr(lib(), "orc_conv_fwd" + sfx)(_p(feat, ptr), ctypes.c_int64(feat.shape[0]), ctypes.c_int(cin),
+                                                  _p(weight, ptr), ctypes.c_int(K), ctypes.c_int(cout),
+                                                  _p(nbr, c_i32p), ctypes.c_int64(n_out), _p(b, ptr), _p(out, ptr))
         assert rc == 0
     return out
 
 
-def conv_dgrad(dout, weight, nbr, n_in):
-    dout, weight, nbr = _f32(dout), _f32(weight), _i32(nbr)
+def conv_dgrad(dout, weight, nbr, n_in, dtype=np.float32):
+    dt, ptr, sfx = _kind(dtype)
+    dout, weight, nbr = _real(dout, dt), _real(weight, dt), _i32(nbr)
     cout, cin = weight.shape[0], weight.shape[-1]
     K, n_out = nbr.shape
-    din = np.zeros((n_in, cin), np.float32)
+    din = np.zeros((n_in, cin), dt)
     if n_in and n_out:
-        lib().orc_conv_dgrad(_p(dout, c_f32p), ctypes.c_int64(n_out), ctypes.c_int(cout),
-                             _p(weight, c_f32p), ctypes.c_int(K), ctypes.c_int(cin),
-                             _p(nbr, c_i32p), ctypes.c_int64(n_in), _p(din, c_f32p))
+        getattr(lib(), "orc_conv_dgrad" + sfx)(_p(dout, ptr), ctypes.c_int64(n_out), ctypes.c_int(cout),
+                                               _p(weight, ptr), ctypes.c_int(K), ctypes.c_int(cin),
+                                               _p(nbr, c_i32p), ctypes.c_int64(n_in), _p(din, ptr))
     return din
 
 
-def conv_wgrad(feat, dout, nbr, wshape, with_bias=False):
-    feat, dout, nbr = _f32(feat), _f32(dout), _i32(nbr)
+def conv_wgrad(feat, dout, nbr, wshape, with_bias=False, dtype=np.float32):
+    dt, ptr, sfx = _kind(dtype)
+    feat, dout, nbr = _real(feat, dt), _real(dout, dt), _i32(nbr)
     cout, cin = wshape[0], wshape[-1]
     K, n_out = nbr.shape
-    dw = np.zeros(wshape, np.float32)
-    db = np.zeros((cout,), np.float32) if with_bias else None
-    lib().orc_conv_wgrad(_p(feat, c_f32p), ctypes.c_int64(feat.shape[0]), ctypes.c_int(cin),
-                         _p(dout, c_f32p), ctypes.c_int64(n_out), ctypes.c_int(cout),
-                         _p(nbr, c_i32p), ctypes.c_int(K), _p(dw, c_f32p), _p(db, c_f32p))
+    dw = np.zeros(wshape, dt)
+    db = np.zeros((cout,), dt) if with_bias else None
+    getattr(lib(), "orc_conv_wgrad" + sfx)(_p(feat, ptr), ctypes.c_int64(feat.shape[0]), ctypes.c_int(cin),
+                                           _p(dout, ptr), ctypes.c_int64(n_out), ctypes.c_int(cout),
+                                           _p(nbr, c_i32p), ctypes.c_int(K), _p(dw, ptr), _p(db, ptr))
     return (dw, db) if with_bias else dw
 
 

@@ -229,3 +229,147 @@ def test_vista_full_net_forward(dev):
             s = float(c[k].abs().max())
             assert float((p[k].cpu() - c[k]).abs().max()) <= 2e-3 * s       # fp32 conv algorithms differ (MIOpen vs CPU)
             assert float((q[k] - p[k]).abs().max()) <= 2e-3 * s
+
+
+def test_vista_frame_multiview_backbone_vs_oracle(dev):
+    """BASELINE configs[2], sparse part, at FULL size: one VISTA frame (grid [101,1280,1280]) through
+    MultiViewBackbone -- fused engine and module path -- against the oracle, both outputs (BEV [1,640,160,160] and
+    RV [1,640,160,12]) within 1e-4 relative, zeros exactly outside the oracle's active sites."""
+    from oracle import backbone_oracle as bo
+    from oracle import voxelize_np as ov
+    from vista_amd import models
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, (rg, vs, T, mv) = _setup("VISTA", [0], 10, dev)
+    mean, coords, nump = voxelize_batch(gen, [torch.from_numpy(clouds[0]).to(dev)])
+    v, c, n = ov.voxelize(clouds[0], vs, rg, T, mv)
+    o_coords = ov.collate_coords([c])
+    np.testing.assert_array_equal(coords.cpu().numpy(), o_coords)
+    np.testing.assert_array_equal(nump.cpu().numpy(), n)
+    o_feat = ov.mean_vfe(v, n)
+    sd = backbone_state_dict("MultiViewBackbone")
+    net = models.load_numpy_state_dict(models.MultiViewBackbone(num_input_features=5), sd).to(dev).eval()
+    bev_o, rv_o, tb, tr = bo.multi_view_backbone(o_feat, o_coords, 1, grid, sd, return_tensors=True)
+    masks = [bo.active_mask(tb), bo.active_mask(tr, "rv")]
+    with torch.no_grad():
+        out_mod = net(mean, coords, 1, grid)
+    out_fused = FusedBackbone(net).forward_frames(gen, [torch.from_numpy(clouds[0]).to(dev)], grid)
+    assert bev_o.shape == (1, 640, 160, 160) and rv_o.shape == (1, 640, 160, 12)
+    for outs in (out_mod, out_fused):
+        for got, ref, act in zip(outs, (bev_o, rv_o), masks):
+            got = got.cpu().numpy()
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+            assert not (got[~act] != 0).any()
+
+
+def test_stress_frame_end_to_end_vs_oracle(dev):
+    """BASELINE configs[3] at FULL size: one 40-sweep cloud (~986 k points) on the 0.05 m grid [41,2160,2160]:
+    voxels bit-exact, backbone output within 1e-4 relative of the oracle (fp32) / 2e-2 (bf16)."""
+    from oracle import backbone_oracle as bo
+    from oracle import voxelize_np as ov
+    from vista_amd import models
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, (rg, vs, T, mv) = _setup("STRESS", [7], 40, dev)
+    frame = torch.from_numpy(clouds[0]).to(dev)
+    mean, coords, nump = voxelize_batch(gen, [frame])
+    v, c, n = ov.voxelize(clouds[0], vs, rg, T, mv)
+    o_coords = ov.collate_coords([c])
+    assert coords.shape[0] > 500_000
+    np.testing.assert_array_equal(coords.cpu().numpy(), o_coords)
+    np.testing.assert_array_equal(nump.cpu().numpy(), n)
+    o_feat = ov.mean_vfe(v, n)
+    np.testing.assert_allclose(mean.cpu().numpy(), o_feat, rtol=1e-6, atol=1e-6)
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).to(dev).eval()
+    ref, t = bo.sp_middle_resnet_fhd(o_feat, o_coords, 1, grid, sd)
+    act = bo.active_mask(t)
+    scale = np.abs(ref).max()
+    out = FusedBackbone(net).forward_frames(gen, [frame], grid).cpu().numpy()
+    assert out.shape == ref.shape == (1, 256, 270, 270)
+    assert np.abs(out - ref).max() <= 1e-4 * scale
+    assert not (out[~act] != 0).any()
+    out16 = FusedBackbone(net, dtype=torch.bfloat16).forward_frames(gen, [frame], grid).float().cpu().numpy()
+    assert np.abs(out16 - ref).max() <= 2e-2 * scale
+
+
+def test_fhd_train_step_vs_oracle(dev):
+    """BASELINE configs[4] at FULL size, one frame: loss of the training forward (train-mode BatchNorm, fused
+    kernels) and the weight gradients of the deep stages (middle_conv.15 and up: the conv 64->128, both 128-channel
+    blocks, the last conv) against torch CPU autograd over the ORACLE's fp32 conv forward / dgrad / wgrad."""
+    from oracle import backbone_oracle as bo  # noqa: F401  (oracle package import check)
+    from oracle import spconv_oracle as so
+    from vista_amd import models
+    from vista_amd.fused_bn import fuse_for_training
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.voxel import voxelize_batch
+    gen, clouds, grid, _ = _setup("FHD", [0], 10, dev)
+    mean, coords, _ = voxelize_batch(gen, [torch.from_numpy(clouds[0]).to(dev)])
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+    net = fuse_for_training(models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).to(dev).train())
+    out = net(mean, coords, 1, grid)
+    loss = (out ** 2).mean()
+    loss.backward()
+    numel = out.numel()
+
+    class OConv(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, nbr):
+            ctx.nbr, ctx.n_in = nbr, x.shape[0]
+            ctx.save_for_backward(x, w)
+            return torch.from_numpy(so.conv_fwd(x.numpy(), w.numpy(), nbr))
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            g = g.contiguous().numpy()
+            din = torch.from_numpy(so.conv_dgrad(g, w.numpy(), ctx.nbr, ctx.n_in)) if ctx.needs_input_grad[0] else None
+            dw = torch.from_numpy(so.conv_wgrad(x.numpy(), g, ctx.nbr, tuple(w.shape))) if ctx.needs_input_grad[1] else None
+            return din, dw, None
+
+    ref = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).train()
+    deep = {n: p for n, p in ref.named_parameters() if int(n.split(".")[1]) >= 15}
+    for n, p in ref.named_parameters():
+        p.requires_grad_(n in deep)               # autograd then stops below middle_conv.15
+    x, c = mean.cpu(), coords.cpu().numpy()
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    cache = {}
+
+    def run_conv(conv, x, c, shape):
+        if conv.subm:
+            key = (conv.indice_key, c.shape[0])
+            if key not in cache:
+                cache[key] = so.rulebook_subm(c, shape, conv.kernel_size)
+            y, oc, osh = OConv.apply(x, conv.weight, cache[key]), c, shape
+        else:
+            oc, nbr, osh = so.rulebook_conv(c, shape, conv.kernel_size, conv.stride, conv.padding)
+            y = OConv.apply(x, conv.weight, nbr)
+        return (y + conv.bias if conv.bias is not None else y), oc, osh
+
+    for m in ref.middle_conv:
+        if isinstance(m, models.SparseBasicBlock):
+            idt = x
+            y, _, _ = run_conv(m.conv1, x, c, shape)
+            y = torch.relu(m.bn1(y))
+            y, _, _ = run_conv(m.conv2, y, c, shape)
+            x = torch.relu(m.bn2(y) + idt)
+        elif hasattr(m, "subm"):
+            x, c, shape = run_conv(m, x, c, shape)
+        else:
+            x = m(x)
+    loss_ref = (x ** 2).sum() / numel
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    got = dict(net.named_parameters())
+    checked = 0
+    for n, p in deep.items():
+        if not (n.endswith("weight") and p.dim() == 5):
+            continue
+        g, r = got[n].grad.cpu().numpy().ravel().astype(np.float64), p.grad.numpy().ravel().astype(np.float64)
+        assert np.abs(g - r).max() <= 1e-3 * np.abs(r).max(), (n, np.abs(g - r).max() / np.abs(r).max())
+        assert float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r))) >= 0.99999, n
+        checked += 1
+    assert checked == 6     # conv 64->128, 2 blocks x 2 convs at 128 channels, the last conv

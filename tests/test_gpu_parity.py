@@ -349,37 +349,32 @@ def test_backbone_forward_vs_oracle(kind, dev):
             assert np.abs(got[diff]).max(initial=0.0) <= 1e-4 * scale and np.abs(r[diff]).max(initial=0.0) <= 1e-4 * scale
 
 
-def test_backbone_train_step_grads_vs_oracle(dev):
-    """One fwd+bwd of SpMiddleResNetFHD (train-mode BN, loss = mean(out^2)) through the autograd
-    wiring of the libvx dgrad/wgrad kernels, against torch autograd over the ORACLE's convs."""
+def _oracle_train_step(sd, mean, coords, grid, numel, dtype, gates=None):
+    """fwd + loss = sum(x^2)/numel + bwd of SpMiddleResNetFHD (train-mode BatchNorm) in torch CPU autograd whose
+    sparse convolutions are the ORACLE's conv fwd/dgrad/wgrad in `dtype` (torch.float32: the reference's precision;
+    torch.float64: the truth). -> (loss, {param name: grad ndarray}). `gates` (a list) receives, per ReLU in call
+    order, (names of the conv weights whose output it gates, bool mask of open gates)."""
     from oracle import spconv_oracle as so
     from vista_amd import models
-    from vista_amd.synth import backbone_state_dict
-    clouds, mean, coords, grid, _ = _tiny_frames(dev, 2)
-    sd = backbone_state_dict("SpMiddleResNetFHD")
-    net = models.SpMiddleResNetFHD(num_input_features=5)
-    models.load_numpy_state_dict(net, sd).to(dev).train()
-    out = net(mean, coords, 2, grid)
-    loss = (out ** 2).mean()
-    loss.backward()
-    # CPU reference: the same network in torch fp32 autograd with the ORACLE's conv fwd/dgrad/wgrad
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+
     class OConv(torch.autograd.Function):
         @staticmethod
         def forward(ctx, x, w, nbr):
             ctx.nbr, ctx.n_in = nbr, x.shape[0]
             ctx.save_for_backward(x, w)
-            return torch.from_numpy(so.conv_fwd(x.numpy(), w.numpy(), nbr))
+            return torch.from_numpy(so.conv_fwd(x.numpy(), w.numpy(), nbr, dtype=npdt))
 
         @staticmethod
         def backward(ctx, g):
             x, w = ctx.saved_tensors
             g = g.contiguous().numpy()
-            return (torch.from_numpy(so.conv_dgrad(g, w.numpy(), ctx.nbr, ctx.n_in)),
-                    torch.from_numpy(so.conv_wgrad(x.numpy(), g, ctx.nbr, tuple(w.shape))), None)
+            return (torch.from_numpy(so.conv_dgrad(g, w.numpy(), ctx.nbr, ctx.n_in, dtype=npdt)),
+                    torch.from_numpy(so.conv_wgrad(x.numpy(), g, ctx.nbr, tuple(w.shape), dtype=npdt)), None)
 
     ref = models.SpMiddleResNetFHD(num_input_features=5)
-    models.load_numpy_state_dict(ref, sd).train()
-    x = mean.cpu()
+    models.load_numpy_state_dict(ref, sd).train().to(dtype)
+    x = mean.cpu().to(dtype)
     c = coords.cpu().numpy()
     shape = [int(v) for v in (np.array(grid[::-1]) + [1, 0, 0])]
     cache = {}
@@ -398,35 +393,100 @@ def test_backbone_train_step_grads_vs_oracle(dev):
             y = y + conv.bias
         return y, oc, osh
 
-    for m in ref.middle_conv:
+    def relu(t, name):
+        y = torch.relu(t)
+        if gates is not None:
+            gates.append((name, (y > 0).numpy()))
+        return y
+
+    pending = None
+    for i, m in enumerate(ref.middle_conv):
         if isinstance(m, models.SparseBasicBlock):
             idt = x
             y, _, _ = run_conv(m.conv1, x, c, shape)
-            y = torch.relu(m.bn1(y))
+            y = relu(m.bn1(y), f"middle_conv.{i}.conv1.weight")
             y, _, _ = run_conv(m.conv2, y, c, shape)
-            x = torch.relu(m.bn2(y) + idt)
+            x = relu(m.bn2(y) + idt, f"middle_conv.{i}.conv2.weight")
         elif hasattr(m, "subm"):
             x, c, shape = run_conv(m, x, c, shape)
+            pending = f"middle_conv.{i}.weight"
+        elif isinstance(m, torch.nn.ReLU):
+            x = relu(x, pending)
         else:
             x = m(x)
     # loss over the dense tensor == sum over active rows / numel(dense)
+    loss = (x ** 2).sum() / numel
+    loss.backward()
+    return float(loss.item()), {n: p.grad.numpy().astype(np.float64) for n, p in ref.named_parameters()}
+
+
+def _gpu_train_step(sd, mean, coords, grid, dev, fused=False):
+    """The same step on the GPU (module path; fused=True: libvx BatchNorm kernels) -> (net, out, loss, gates)."""
+    from vista_amd import models
+    from vista_amd.fused_bn import FusedBatchNorm1d, fuse_for_training
+    net = models.SpMiddleResNetFHD(num_input_features=5)
+    models.load_numpy_state_dict(net, sd).to(dev).train()
+    if fused:
+        fuse_for_training(net)
+    gates = []
+    hooks = []
+    for m in net.modules():
+        if isinstance(m, torch.nn.ReLU) or (isinstance(m, FusedBatchNorm1d) and m.relu):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out: gates.append((out > 0).cpu().numpy())))
+    out = net(mean, coords, 2, grid)
+    loss = (out ** 2).mean()
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    return net, out, loss, gates
+
+
+def _check_grads_against_fp64(net, gates, gates64, g32, g64):
+    """A weight gradient depends on the ReLU gates of its own layer and of every layer above it. Where the GPU run's
+    gates all agree with the fp64 run's, the gradient must match fp64 to 1e-4 (fp32 rounding only). A gate that
+    flips (a pre-activation within rounding of zero: fp32 and fp64 land on different sides) is a discontinuity, not
+    an error: below the first flip only direction and size are checked -- the fp32 CPU oracle shows the same
+    step-like behaviour at ITS first flip (tools/grad_error_table.py)."""
+    assert len(gates) == len(gates64) == 21
+    flips_from = {}                    # conv weight name -> gates flipped at its ReLU or any later one
+    later = 0
+    for (name, m64), m in zip(gates64[::-1], gates[::-1]):
+        later += int((m64 != m).sum())
+        flips_from[name] = later
+    tight = 0
+    for n, p in net.named_parameters():
+        if not (n.endswith("weight") and p.dim() == 5):
+            continue
+        g = p.grad.cpu().numpy().astype(np.float64)
+        scale = np.abs(g64[n]).max()
+        err = np.abs(g - g64[n]).max() / scale
+        cos = float(g.ravel() @ g64[n].ravel() / (np.linalg.norm(g) * np.linalg.norm(g64[n])))
+        if flips_from[n] == 0:
+            assert err <= 1e-4, (n, err)
+            tight += 1
+        else:
+            assert cos >= 0.9995 and err <= 5e-2, (n, cos, err, flips_from[n])
+        if int(n.split(".")[1]) >= 15:   # deep stages also against the fp32 oracle itself
+            assert np.abs(g - g32[n]).max() / np.abs(g32[n]).max() <= 1e-3, n
+    return tight
+
+
+def test_backbone_train_step_grads_vs_oracle(dev):
+    """One fwd+bwd of SpMiddleResNetFHD (train-mode BN, loss = mean(out^2)) through the autograd wiring of the libvx
+    dgrad/wgrad kernels, against torch autograd over the ORACLE's convs in fp32 (the oracle proper) and in fp64 (the
+    truth). See _check_grads_against_fp64 for the bar: 1e-4 against fp64 wherever the ReLU gate pattern agrees."""
+    from vista_amd.synth import backbone_state_dict
+    clouds, mean, coords, grid, _ = _tiny_frames(dev, 2)
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+    net, out, loss, gates = _gpu_train_step(sd, mean, coords, grid, dev)
     numel = out.numel()
-    loss_ref = (x ** 2).sum() / numel
-    loss_ref.backward()
-    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
-    # Weight gradients. The deep stages must agree to fp32 rounding. Shallower layers sit behind
-    # ~20 train-mode BatchNorm backward passes whose 1/sqrt(var+eps) factors amplify rounding noise
-    # of near-constant channels: torch CPU fp32 vs fp64 of this same network differs by up to ~1e-2
-    # there (measured, tools/grad_conditioning.py), so those get a direction + loose magnitude check.
-    convs = [(n, p) for n, p in net.named_parameters() if n.endswith("weight") and p.dim() == 5]
-    rconvs = dict(ref.named_parameters())
-    for n, p in convs:
-        g, r = p.grad.cpu().numpy().ravel(), rconvs[n].grad.numpy().ravel()
-        rel = np.abs(g - r).max() / np.abs(r).max()
-        cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r)))
-        stage = int(n.split(".")[1])
-        assert rel <= (1e-3 if stage >= 15 else 5e-2), (n, rel)
-        assert cos >= 0.9995, (n, cos)
+    gates64 = []
+    loss32, g32 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float32)
+    loss64, g64 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float64, gates64)
+    assert abs(loss.item() - loss32) <= 1e-4 * abs(loss32)
+    assert abs(loss.item() - loss64) <= 1e-4 * abs(loss64)
+    tight = _check_grads_against_fp64(net, gates, gates64, g32, g64)
+    assert tight >= 7, tight             # at least the 128-channel stage, the conv into it and the last conv
 
 
 # ---------------------------------------------------------------------------- bf16

@@ -127,3 +127,34 @@ def test_pairs_view_and_empty():
     assert set(np.unique(nbr[nbr >= 0])) == set(range(coords.shape[0]))
     oc0, nbr0, _ = so.rulebook_conv(np.zeros((0, 4), np.int32), [5, 6, 7], 3, 2, 1)
     assert oc0.shape == (0, 4) and nbr0.shape == (27, 0)
+
+
+@pytest.mark.parametrize("ks,st,pd", [GEOMS[0], GEOMS[4]])
+def test_fp64_oracle_variant_against_dense_autograd(ks, st, pd):
+    """The _f64 routines (the truth GPU gradient tests measure rounding error against) agree with dense float64
+    conv3d + autograd to float64 rounding, and the fp32 oracle agrees with them to fp32 rounding."""
+    rng = np.random.default_rng(4)
+    batch, shape, cin, cout = 1, [7, 10, 9], 4, 5
+    coords = random_sites(rng, batch, shape, 120)
+    feat = rng.normal(size=(coords.shape[0], cin))
+    w = rng.normal(size=(cout, *ks, cin))
+    bias = rng.normal(size=(cout,))
+    oc, nbr, osh = so.rulebook_conv(coords, shape, ks, st, pd)
+    dout = rng.normal(size=(oc.shape[0], cout))
+    out = so.conv_fwd(feat, w, nbr, bias, dtype=np.float64)
+    din = so.conv_dgrad(dout, w, nbr, coords.shape[0], dtype=np.float64)
+    dw, db = so.conv_wgrad(feat, dout, nbr, w.shape, with_bias=True, dtype=np.float64)
+    assert out.dtype == din.dtype == dw.dtype == db.dtype == np.float64
+    x = densify(feat, coords, batch, shape).requires_grad_(True)
+    wt = w_dense(w).requires_grad_(True)
+    y = F.conv3d(x, wt, torch.as_tensor(bias), stride=st, padding=pd)
+    y.backward(densify(dout, oc, batch, osh))
+    c, o = torch.as_tensor(coords).long(), torch.as_tensor(oc).long()
+    np.testing.assert_allclose(out, y.detach()[o[:, 0], :, o[:, 1], o[:, 2], o[:, 3]].numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(din, x.grad[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]].numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dw, wt.grad.permute(0, 2, 3, 4, 1).numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(db, dout.sum(0), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(so.conv_fwd(feat, w, nbr, bias), out, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(so.conv_dgrad(dout, w, nbr, coords.shape[0]), din, rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        so.conv_fwd(feat, w, nbr, bias, dtype=np.float16)
