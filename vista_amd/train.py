@@ -48,7 +48,7 @@ def allreduce_grads_flat(params, dist=None, world=1):
     ref = next((p.grad for p in params if p.grad is not None), params[0])
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p, dtype=ref.dtype)).reshape(-1)
                       for p in params])
-    if dist is not None and world > 1:
+    if dist is not None:
         _all_reduce_sum(flat, dist)
         flat.div_(world)
         off = 0
@@ -136,7 +136,7 @@ class GradBuckets:
         self.next += 1
         self.fired[b] = True
         self.log.append((b, why))
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None:
             lo, hi = self.bounds[b]
             w = _all_reduce_sum(self.flat[lo:hi], self.dist, async_op=True)
             if w is not None:
