@@ -213,6 +213,11 @@ int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, const void*
 int32_t vx_to_dense(const void* d_feat, const int32_t* d_coords, int64_t n, int32_t c,
                     int32_t batch, const int32_t* shape, void* d_dense, int32_t dtype,
                     void* stream);
+/* The gradient of dense(): d_feat[row][:] = d_dense[b][:,z,y,x] at row's coordinates (rows of out-of-grid coordinates
+ * are the caller's error, as for vx_to_dense). Replaces the scatter's autograd gather reached through
+ * loss.backward() (det3d/core/utils/dist_utils.py:50-56) behind scn.py:375. */
+int32_t vx_from_dense(const void* d_dense, const int32_t* d_coords, int64_t n, int32_t c, int32_t batch,
+                      const int32_t* shape, void* d_feat, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * "_dn" forms: the same operations with their data-dependent ROW COUNTS RESIDENT ON THE DEVICE, so that the whole

@@ -20,9 +20,10 @@ class _SparseConvFn(torch.autograd.Function):
     """out = conv(features, weight) + bias over a rulebook; dgrad/wgrad are the libvx kernels."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb):
+    def forward(ctx, features, weight, bias, rb, bias_grad_zero=False):
         ctx.rb = rb
         ctx.has_bias = bias is not None
+        ctx.bias_grad_zero = bias_grad_zero
         ctx.save_for_backward(features, weight)
         return vx.conv_fwd(features, weight, rb, bias=bias)
 
@@ -37,8 +38,10 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = vx.conv_wgrad(features, grad_out, rb, weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = grad_out.sum(0)
-        return din, dw, db, None
+            # in front of a batch-statistics norm the column sums of grad_out are zero by construction (the norm
+            # subtracts the batch mean, SyncBatchNorm the global one): write the zeros, skip the reduction
+            db = grad_out.new_zeros(grad_out.shape[1]) if ctx.bias_grad_zero else grad_out.sum(0)
+        return din, dw, db, None, None
 
 
 def convert_weight(w, layout):
@@ -79,6 +82,7 @@ class SparseConvolution(SparseModule):
             self.bias = nn.Parameter(torch.empty(self.out_channels))
         else:
             self.register_parameter("bias", None)
+        object.__setattr__(self, "norm_after", None)    # set by vista_amd.fused_bn (not a submodule of the conv)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -136,7 +140,8 @@ class SparseConvolution(SparseModule):
             raise ValueError(f"expected {self.in_channels} input channels, got {feats.shape[1]}")
         rb = self._rulebook(input)
         weight = self.weight if self.weight.dtype == feats.dtype else self.weight.to(feats.dtype)
-        out_feats = _SparseConvFn.apply(feats, weight, self.bias, rb)
+        norm = self.norm_after
+        out_feats = _SparseConvFn.apply(feats, weight, self.bias, rb, norm is not None and norm.training)
         out = SparseConvTensor(out_feats, input.indices if self.subm else rb.out_indices,
                                input.spatial_shape if self.subm else rb.out_shape, input.batch_size,
                                input.grid, input.voxel_num, input.indice_dict, input.benchmark)

@@ -83,10 +83,10 @@ class _ToDense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, indices, batch_size, spatial_shape):
         ctx.save_for_backward(indices)
+        ctx.spatial_shape = spatial_shape
         return vx.to_dense(features, indices, batch_size, spatial_shape)
 
     @staticmethod
     def backward(ctx, grad):
         (idx,) = ctx.saved_tensors
-        i = idx.long()
-        return grad[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous(), None, None, None
+        return vx.from_dense(grad, idx, ctx.spatial_shape), None, None, None

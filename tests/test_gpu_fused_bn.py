@@ -172,6 +172,67 @@ def test_fuse_for_training_matches_module_path(dev):
             assert cos >= 0.999, (n, cos, rel)
 
 
+def test_conv_bias_gradient_in_front_of_a_training_norm_is_written_as_zero(dev):
+    """fuse_for_training tells every biased conv whose output a BatchNorm consumes; in training mode its backward
+    writes exact zeros for the bias gradient (the reduction over rows it skips yields rounding noise around zero:
+    checked here against the unfused path, relative to the size of the terms that cancel) and leaves every other
+    gradient bitwise as it was. In eval mode the norm is affine and the bias gradient is reduced as before."""
+    from test_gpu_parity import _tiny_frames
+    from vista_amd import models
+    from vista_amd.fused_bn import fuse_for_training
+    from vista_amd.synth import backbone_state_dict
+    import spconv.pytorch as spconv
+    clouds, mean, coords, grid, _ = _tiny_frames(dev, 2)
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+
+    def run(skip, train=True):
+        net = fuse_for_training(models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).to(dev))
+        net.train(train)
+        told = [m for m in net.modules() if isinstance(m, spconv.SparseConvolution) and m.norm_after is not None]
+        assert len(told) == 16 and all(m.bias is not None for m in told)      # the two convs of each of 8 blocks
+        if not skip:
+            for m in told:
+                object.__setattr__(m, "norm_after", None)
+        out = net(mean, coords, 2, grid)
+        (out ** 2).mean().backward()
+        return net, {n: p.grad.clone() for n, p in net.named_parameters()}, {id(m.bias) for m in told}
+
+    net, g_skip, told = run(True)
+    _, g_full, _ = run(False)
+    names = {n for n, p in net.named_parameters() if id(p) in told}
+    assert len(names) == 16
+    for n in g_full:
+        if n in names:
+            assert float(g_skip[n].abs().max()) == 0.0
+            w = g_full[n.replace("bias", "weight")]
+            assert float(g_full[n].abs().max()) <= 1e-4 * float(w.abs().max()) + 1e-12, n   # noise, not signal
+        else:
+            assert torch.equal(g_skip[n], g_full[n]), n
+    net_e, g_eval, told_e = run(True, train=False)
+    for n, p in net_e.named_parameters():
+        if id(p) in told_e:
+            assert float(g_eval[n].abs().max()) > 0.0, n
+
+
+def test_from_dense_is_the_gather_of_to_dense(dev):
+    from vista_amd import ops
+    rng = np.random.default_rng(3)
+    for c, dt in ((128, torch.float32), (64, torch.bfloat16), (5, torch.float32)):
+        shape, batch = [2, 37, 41], 3
+        cells = batch * shape[0] * shape[1] * shape[2]
+        lin = np.sort(rng.choice(cells, size=1777, replace=False))
+        idx = np.stack([lin // (shape[0] * shape[1] * shape[2]), (lin // (shape[1] * shape[2])) % shape[0],
+                        (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+        idx = torch.from_numpy(idx).to(dev)
+        dense = torch.randn((batch, c, *shape), device=dev).to(dt)
+        got = ops.from_dense(dense, idx, shape)
+        i = idx.long()
+        ref = dense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]]
+        assert torch.equal(got, ref)
+        assert torch.equal(ops.from_dense(ops.to_dense(got, idx, batch, shape), idx, shape), got)
+    assert ops.from_dense(dense, idx[:0], shape).shape == (0, 5)
+
+
 def test_fused_sync_bn_two_ranks_equal_one_rank_on_all_rows(dev):
     """sync=True on two "ranks" holding uneven shards of the rows == one unsynchronised module over all rows:
     statistics, outputs and input gradients agree, parameter gradients add up over ranks (SyncBatchNorm semantics,

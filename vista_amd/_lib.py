@@ -75,6 +75,7 @@ SIGNATURES = {
     "vx_spconv_fwd_dn": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                    c_int32, c_void_p]),
+    "vx_from_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p, c_int32, c_void_p]),
     "vx_to_dense_dn": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
                                  c_int32, c_void_p]),
     "vx_bn_workspace_bytes": (c_size_t, [c_int32]),

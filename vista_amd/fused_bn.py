@@ -122,6 +122,8 @@ class FusedSparseBasicBlock(spconv.SparseModule):
         self.conv2 = blk.conv2
         self.bn2 = FusedBatchNorm1d.from_bn(blk.bn2, True, sync, process_group)
         self.downsample, self.stride = blk.downsample, blk.stride
+        _norm_follows(self.conv1, self.bn1)
+        _norm_follows(self.conv2, self.bn2)
 
     def forward(self, x):
         y = self.conv1(x)
@@ -129,6 +131,15 @@ class FusedSparseBasicBlock(spconv.SparseModule):
         y = self.conv2(y)
         skip = x if self.downsample is None else self.downsample(x)
         return y.replace_feature(self.bn2(y.features, residual=skip.features))
+
+
+def _norm_follows(conv, bn):
+    """Tell a sparse conv that `bn` consumes its output directly: while bn is in training mode the conv's bias
+    gradient is identically zero (d loss / d bias = column sums of the norm's input gradient, which the mean
+    subtraction makes vanish), so its backward writes zeros instead of reducing grad_out over the rows. The bias
+    keeps requires_grad and its place in the optimizer (weight decay still applies, as in the reference)."""
+    if isinstance(conv, spconv.SparseConvolution) and conv.bias is not None:
+        object.__setattr__(conv, "norm_after", bn)
 
 
 def fuse_for_training(module, sync=False, process_group=None):
@@ -148,6 +159,8 @@ def fuse_for_training(module, sync=False, process_group=None):
                     nxt = child._modules[names[i + 1]] if i + 1 < len(names) else None
                     relu = type(nxt) is nn.ReLU
                     child._modules[nm] = FusedBatchNorm1d.from_bn(m, relu, sync, process_group)
+                    if i > 0:
+                        _norm_follows(child._modules[names[i - 1]], child._modules[nm])
                     if relu:
                         child._modules[names[i + 1]] = nn.Identity()
             fuse_for_training(child, sync, process_group)

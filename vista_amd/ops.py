@@ -405,6 +405,23 @@ def to_dense(features, indices, batch_size, spatial_shape, out=None):
     return dense
 
 
+def from_dense(dense, indices, spatial_shape):
+    """The gradient of to_dense: dense [B, C, D, H, W] contiguous -> [n, C] rows gathered at `indices`."""
+    _need_gpu(dense, "dense")
+    dense = dense.contiguous()
+    indices = indices.contiguous()
+    sh = triple(spatial_shape)
+    if dense.dim() != 5 or list(dense.shape[2:]) != sh or dense.dtype not in _DT:
+        raise ValueError(f"dense must be [B, C, {sh[0]}, {sh[1]}, {sh[2]}] in float32 or bfloat16")
+    n, c = indices.shape[0], dense.shape[1]
+    out = torch.empty((n, c), dtype=dense.dtype, device=dense.device)
+    with torch.cuda.device(dense.device):
+        rc = L.lib().vx_from_dense(_ptr(dense), _ptr(indices), n, c, dense.shape[0], L.i32x3(sh), _ptr(out),
+                                   _DT[dense.dtype], _stream())
+    L.check(rc, "vx_from_dense")
+    return out
+
+
 def conv_wgrad(features, grad_out, rb, weight_shape):
     """-> dW float32 with the KRSC shape of the weight."""
     _need_gpu(features, "features")
