@@ -29,6 +29,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense matrix peak (the chip holds a lower clock under bf16 load)
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
@@ -195,7 +196,19 @@ def dominant_kernel_roofline(timing, dtype):
     common = {"launches": int(len(sel)), "avg_launch_ms": float(ms.mean()), "flops_per_launch": float(flops.mean()),
               "achieved_tflops": tflops, "symbol_launches": int(len(sym)), "symbol_avg_launch_ms": float(sym.mean())}
     if dtype == "fp32":
-        # fp32: intensity Cout/2 = 64 flop per gathered byte -> MFMA-bound (157.3 TFLOP/s fp32 matrix peak)
+        from vista_amd import _lib
+        products = int(_lib.lib().vx_spconv_get_f32_products())
+        if products:
+            # fp32 operands split exactly into three bf16 planes, `products` plane products per fp32 product on the bf16
+            # matrix pipe (fp32 accumulate): the bound is the bf16 MFMA peak divided by the MFMAs spent per product
+            peak = PEAK_BF16_MFMA_TFLOPS / products
+            return {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                    "peak_basis": f"bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {products} plane products "
+                                  "per fp32 product (algorithmic fp32 flops)",
+                    "frac_of_fp32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(f"f32_split{products}"),
+                    "kernel": f"spconv_w8s body, <128,128,{products}> (SubMConv3d 128->128, k=3; fp32 in/out/accumulate)",
+                    **common}
+        # fp32 MFMA: intensity Cout/2 = 64 flop per gathered byte -> MFMA-bound (157.3 TFLOP/s fp32 matrix peak)
         return {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("f32"),
                 "kernel": "spconv_w8 body, <float,128,128> (SubMConv3d 128->128, k=3)", **common}
@@ -385,7 +398,7 @@ def run_infer(a, dev, rank, world, dist, backend, barrier):
         "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16",
-        "data": "synthetic",
+        "data": "synthetic", "f32_matrix_arithmetic": f32_arithmetic_name(),
         "config": {"workload": f"{a.geometry} {sweeps}-sweep synthetic nuScenes-shaped frames, sparse_shape "
                                f"{[grid[2] + 1, grid[1], grid[0]]}, batch {a.batch}/GPU, inference, "
                                f"inputs resident in HBM (BASELINE.json {cfg_name})",
@@ -405,8 +418,26 @@ def run_infer(a, dev, rank, world, dist, backend, barrier):
     return res, (gen, grid, engine, frames, tail)
 
 
-def infer_variant(a, dev, rank, dtype_name, geometry, batch, steps, want_roofline=False, want_phases=False):
+def f32_arithmetic_name():
+    from vista_amd import _lib
+    p = int(_lib.lib().vx_spconv_get_f32_products())
+    return ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if p == 0 else
+            f"fp32 operands split exactly into 3 bf16 planes, {p} of 9 plane products on v_mfma_f32_32x32x16_bf16, "
+            "fp32 accumulate (Cin >= 64 layers; error vs fp64 <= the fp32 MFMA's, tests/test_gpu_f32_products.py)")
+
+
+def infer_variant(a, dev, rank, dtype_name, geometry, batch, steps, want_roofline=False, want_phases=False,
+                  f32_products=None):
     """One more configuration of BASELINE.json through the same code, for the `variants` object."""
+    if f32_products is not None:
+        from vista_amd import ops
+        old = ops.set_f32_products(f32_products)
+        try:
+            out = infer_variant(a, dev, rank, dtype_name, geometry, batch, steps, want_roofline, want_phases)
+            out["f32_matrix_arithmetic"] = f32_arithmetic_name()
+        finally:
+            ops.set_f32_products(old)
+        return out
     gen, grid, engine, frames = build_infer(a, dev, rank, dtype_name, geometry, batch)
     step = make_step(a, gen, grid, engine, frames)
     dt, _, _ = timed_infer(step, steps, 2, lambda: None)
@@ -454,6 +485,11 @@ def main():
             if default_cfg:
                 # the other single-GPU configurations BASELINE.json names, through the same code
                 v = res["variants"]
+                # the same fp32 workload on the fp32 MFMA and with all nine plane products
+                v["f32_mfma_batch8"] = infer_variant(a, dev, rank, "fp32", "FHD", a.batch, a.steps, want_roofline=True,
+                                                     f32_products=0)
+                v["f32_split9_batch8"] = infer_variant(a, dev, rank, "fp32", "FHD", a.batch, a.steps,
+                                                       want_roofline=True, f32_products=9)
                 v["bf16_batch8"] = infer_variant(a, dev, rank, "bf16", "FHD", a.batch, a.steps, want_roofline=True)
                 v["bf16_batch1"] = infer_variant(a, dev, rank, "bf16", "FHD", 1, st)
                 v["stress_batch1"] = infer_variant(a, dev, rank, "fp32", "STRESS", 1, 5, want_phases=True)

