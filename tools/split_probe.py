@@ -36,7 +36,7 @@ for cin, cout in ((128, 128), (64, 128), (128, 64)):
     nbr = rb.nbr[:, :nsub].cpu().numpy()
     ref = orc.conv_fwd(x, w, nbr, dtype=np.float64)
     mag = orc.conv_fwd(np.abs(x), np.abs(w), nbr, dtype=np.float64)          # sum |a||b| per output
-    for mode in (0, 9, 6):
+    for mode in [int(m) for m in os.environ.get("VX_PROBE_MODES", "0,9,6").split(",")]:
         ops.set_f32_products(mode)
         for _ in range(2):
             out = ops.conv_fwd(xd, wd, rb, compact=False)

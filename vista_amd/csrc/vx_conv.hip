@@ -12,6 +12,7 @@
 #include <atomic>
 #include <mutex>
 #include <set>
+#include <type_traits>
 #include <utility>
 
 #include "vx_common.h"
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 
 #ifndef VX_ABL
 #define VX_ABL 0
+#endif
+#ifndef VX_W8S_WMID
+#define VX_W8S_WMID 1
 #endif
 #ifndef VX_F32_PRODUCTS_DEFAULT
 #define VX_F32_PRODUCTS_DEFAULT 6
@@ -623,10 +627,12 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
     for (int t = 0; t < 4; ++t) {
       const int row = 8 * t + arow;
       const int idx = sIdx[g * 32 + row];
-#if VX_ABL == 1   // timing-only builds (results wrong by construction): no gathers
+#if VX_ABL == 1 || VX_ABL == 6   // timing-only builds (results wrong by construction): no gathers
       ra[t] = f32x4{(float)idx, (float)ch, 0.f, 0.f};
 #elif VX_ABL == 5  // gathers from the zero row only
       ra[t] = *reinterpret_cast<const f32x4*>(zero + (idx & 3));
+#elif VX_ABL == 8  // gathers from the tile's own rows (sequential addresses)
+      ra[t] = *reinterpret_cast<const f32x4*>(in + (row0 + row + (idx & 1)) * CIN + ch);
 #else
       const float* src = idx >= 0 ? in + (long long)idx * CIN + ch : zero;
       ra[t] = *reinterpret_cast<const f32x4*>(src);
@@ -649,8 +655,13 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
       const int woc = ((int)threadIdx.x + i * NTHR) >> 2;
       const int goc = col0 + woc;
       const bool ok = woc < COUT_PAD && goc < a.cout;
+#if VX_ABL == 9   // chunk-major W image (timing only: reads the wrong elements)
+      const float* src = ok ? wgt + (long long)c * (COUT_PAD * kSChunk) + woc * kSChunk + 8 * wq : zero;
+      (void)g; (void)ch;
+#else
       const float* src = ok ? wgt + ((long long)goc * a.kvol + g) * CIN + ch : zero;
-#if VX_ABL == 2   // no W loads
+#endif
+#if VX_ABL == 2 || VX_ABL == 6   // no W loads
       rw[2 * i] = f32x4{(float)g, (float)ch, 1.f, 0.f};
       rw[2 * i + 1] = rw[2 * i];
       (void)src;
@@ -672,12 +683,12 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
       *reinterpret_cast<bf16x8*>(dst + 2 * COUT_PAD * kSPlaneRow) = p.l;
     }
   };
-  auto mfma_chunk = [&](int buf) {
+  auto mfma_steps = [&](int buf, auto s_begin, auto s_end) {
     const char* pa = sA + buf * ABUF + r * kSRowBytes;
     const char* pb = smem_raw + buf * WBUF + r * kSPlaneRow;
     const int ka = (r >> 1) & 7, kb = (r >> 2) & 3;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = decltype(s_begin)::value; s < decltype(s_end)::value; ++s) {
       const int q = 4 * s + 2 * h;
 #if VX_ABL == 4   // no split of the gathered fragments
       Planes A;
@@ -739,15 +750,31 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
     load_a(cl);
   }
   __syncthreads();
+  // The two waves of a SIMD (w and w + NW/2) take the two halves of a trip in opposite order, so that one stages and
+  // issues loads while the other feeds the matrix pipe.
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
   while (c < nchunks) {
-    store_a(buf ^ 1);
-    store_w(buf ^ 1);
     const int cnn = cn < nchunks ? next_chunk(cn) : cn;
     const int cl = cnn < nchunks ? cnn : c;
+    const bool used = chunk_used(wmask, c);
+    store_a(buf ^ 1);
+    store_w(buf ^ 1);
+#if VX_W8S_WMID   // the W loads go out between the two MFMA steps, the gathers before the first
+    load_a(cl);
+    __builtin_amdgcn_sched_barrier(0);
+    if (used) mfma_steps(buf, I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(cl);
+    __builtin_amdgcn_sched_barrier(0);
+    if (used) mfma_steps(buf, I1{}, I2{});
+#else
     load_w(cl);
     load_a(cl);
 #if VX_ABL != 3   // 3: no MFMA stream
-    if (chunk_used(wmask, c)) mfma_chunk(buf);
+    if (used) mfma_steps(buf, I0{}, I2{});
+#endif
 #endif
     __syncthreads();
     buf ^= 1;
@@ -1214,9 +1241,22 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 #ifndef VX_CB16
 #define VX_CB16 1
 #endif
-template <int CIN, int COUT_PAD, int WAVES>
+// NP = 6 / 9: the split-bf16 arithmetic of spconv_w8s (three exact bf16 planes per fp32 operand, NP plane products on
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation). W_k is split once per workgroup when it is staged (three plane images
+// [Cout][CIN * 2 + 16 B]: the 16 rows of a fragment read land on 16 different bank groups), the gathered rows by the
+// wave that fetched them; lane (n, kq) feeds its channels [16 kq + 8 s, 16 kq + 8 s + 8) to MFMA s as k-group kq.
+template <int CIN, int COUT_PAD, int NP>
+constexpr size_t cb16_w_bytes() {   // one W buffer
+  return NP ? (size_t)3 * COUT_PAD * (CIN * 2 + 16) : (size_t)COUT_PAD * (CIN * 4 + 16);
+}
+
+template <int CIN, int COUT_PAD, int WAVES, int NP = 0>
 __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long row_base, long long ntiles, int part) {
   constexpr int kCbRows = 16 * WAVES, kCbThreads = 64 * WAVES;
+  static_assert(NP == 0 || ((NP == 6 || NP == 9) && CIN == 64), "split form: Cin = 64");
+  constexpr int P_ROW = CIN * 2 + 16;                // padded W row of one bf16 plane image (bytes)
+  constexpr int P_PLANE = COUT_PAD * P_ROW;
+  constexpr int W_BUF = (int)cb16_w_bytes<CIN, COUT_PAD, NP>();
   static_assert(kCbRows % 64 == 0 && COUT_PAD % 16 == 0 && CIN % 16 == 0, "tile shape");
   constexpr int NE = kCbRows / 64;                   // neighbour entries per producer lane
   constexpr int NT = COUT_PAD / 16;                  // 16-channel output tiles (a wave computes all of them)
@@ -1229,8 +1269,8 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
   constexpr int ACC_LD = COUT_PAD + 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sAcc = reinterpret_cast<float*>(smem_raw);                       // [(R + 1)][ACC_LD], row R = dump
-  char* sWb = smem_raw + (kCbRows + 1) * ACC_LD * 4;                      // 2 x [COUT_PAD][W_ROW]
-  int2* sList = reinterpret_cast<int2*>(sWb + 2 * COUT_PAD * W_ROW);      // 2 x [R] (input row + 1, output row + 1)
+  char* sWb = smem_raw + (kCbRows + 1) * ACC_LD * 4;                      // 2 x [COUT_PAD][W_ROW] (or 2 x 3 planes)
+  int2* sList = reinterpret_cast<int2*>(sWb + 2 * W_BUF);                 // 2 x [R] (input row + 1, output row + 1)
   int* sCnt = reinterpret_cast<int*>(sList + 2 * kCbRows);                // 2 pair counts
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1296,26 +1336,50 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
 #pragma unroll
     for (int q = 0; q < QK; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + 16 * q);
   };
-  f32x4 rw[W_LD];
+  constexpr int W_P8 = COUT_PAD * CIN / 8;           // split form: 8-value pieces of W_k, one per thread
+  static_assert(NP == 0 || W_P8 <= kCbThreads, "one W piece per thread");
+  f32x4 rw[NP ? 2 : W_LD];
   auto load_w = [&](int ks) {
     const int kk = ks < a.kvol ? ks : a.kvol - 1;
-#pragma unroll
-    for (int t = 0; t < W_LD; ++t) {
-      const int e = t * kCbThreads + (int)threadIdx.x;
-      const int oc = e / QR, q = e % QR;
+    if constexpr (NP != 0) {
+      const int e = (int)threadIdx.x;
+      const int oc = e / (CIN / 8), p8 = e % (CIN / 8);
       const int goc = col0 + oc;
-      const bool ok = e < W_Q && goc < a.cout;
-      const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * 4 + 16 * q : zero;
-      rw[t] = *reinterpret_cast<const f32x4*>(src);
+      const bool ok = e < W_P8 && goc < a.cout;
+      const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * 4 + 32 * p8 : zero;
+      rw[0] = *reinterpret_cast<const f32x4*>(src);
+      rw[1] = *reinterpret_cast<const f32x4*>(src + 16);
+    } else {
+#pragma unroll
+      for (int t = 0; t < W_LD; ++t) {
+        const int e = t * kCbThreads + (int)threadIdx.x;
+        const int oc = e / QR, q = e % QR;
+        const int goc = col0 + oc;
+        const bool ok = e < W_Q && goc < a.cout;
+        const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * 4 + 16 * q : zero;
+        rw[t] = *reinterpret_cast<const f32x4*>(src);
+      }
     }
   };
   auto store_w = [&](int buf) {
-    char* sW = sWb + buf * COUT_PAD * W_ROW;
+    char* sW = sWb + buf * W_BUF;
+    if constexpr (NP != 0) {
+      const int e = (int)threadIdx.x;
+      if (e < W_P8) {
+        const int oc = e / (CIN / 8), p8 = e % (CIN / 8);
+        const Planes p = split8(rw[0], rw[1]);
+        char* dst = sW + oc * P_ROW + 16 * p8;
+        *reinterpret_cast<bf16x8*>(dst) = p.h;
+        *reinterpret_cast<bf16x8*>(dst + P_PLANE) = p.m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * P_PLANE) = p.l;
+      }
+    } else {
 #pragma unroll
-    for (int t = 0; t < W_LD; ++t) {
-      const int e = t * kCbThreads + (int)threadIdx.x;
-      const int oc = e / QR, q = e % QR;
-      if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
+      for (int t = 0; t < W_LD; ++t) {
+        const int e = t * kCbThreads + (int)threadIdx.x;
+        const int oc = e / QR, q = e % QR;
+        if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
+      }
     }
   };
   auto acc_row = [&](int row_p1) {   // empty slots add zeros to the dump row
@@ -1337,8 +1401,39 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
     f32x4 d[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) d[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const char* pb = sWb + buf * COUT_PAD * W_ROW + n16 * W_ROW + kq * CIN;   // kq * (CIN / 4) floats
     float* arowP = acc_row(rowP);
+    if constexpr (NP != 0) {
+      static_assert(QK == 4, "two 8-value k-groups per lane");
+      const Planes g[2] = {split8(ra[0], ra[1]), split8(ra[2], ra[3])};
+      const char* pw = sWb + buf * W_BUF + n16 * P_ROW + kq * (CIN / 2);   // kq * (CIN / 4) bf16 values
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4 old = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (haveP) old = *reinterpret_cast<const f32x4*>(arowP + t * 16);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const char* q0 = pw + t * 16 * P_ROW + 16 * s2;
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(q0);
+          const bf16x8 wm = *reinterpret_cast<const bf16x8*>(q0 + P_PLANE);
+          const bf16x8 wl = *reinterpret_cast<const bf16x8*>(q0 + 2 * P_PLANE);
+#define VX_MMA16(A, B) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, d[t], 0, 0, 0)
+          if constexpr (NP == 9) {
+            VX_MMA16(wl, g[s2].l);
+            VX_MMA16(wm, g[s2].l);
+            VX_MMA16(wl, g[s2].m);
+          }
+          VX_MMA16(wm, g[s2].m);
+          VX_MMA16(wh, g[s2].l);
+          VX_MMA16(wl, g[s2].h);
+          VX_MMA16(wh, g[s2].m);
+          VX_MMA16(wm, g[s2].h);
+          VX_MMA16(wh, g[s2].h);
+#undef VX_MMA16
+        }
+        if (haveP) *reinterpret_cast<f32x4*>(arowP + t * 16) = old + dP[t];
+      }
+    } else {
+    const char* pb = sWb + buf * COUT_PAD * W_ROW + n16 * W_ROW + kq * CIN;   // kq * (CIN / 4) floats
 #pragma unroll
     for (int q = 0; q < QK; ++q) {
       f32x4 old = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1359,6 +1454,7 @@ __global__ __launch_bounds__(64 * WAVES) void spconv_cb16(ConvArgs a, long long 
         for (int t = 0; t < 2; ++t) d[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t].w, ra[q].w, d[t0 + t], 0, 0, 0);
       }
       if (haveP) *reinterpret_cast<f32x4*>(arowP + q * 16) = old + dP[q];
+    }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) dP[t] = d[t];
@@ -1450,14 +1546,15 @@ int32_t set_lds_once(const void* kern, size_t lds) {
 int cu_count();
 std::atomic<int>& f32_products_mode();
 
-template <int CIN, int COUT_PAD, int WAVES>
+template <int CIN, int COUT_PAD, int WAVES, int NP>
 int32_t launch_cb16_rows(const ConvArgs& a, long long row_base, long long n_tiles, int part, hipStream_t stream) {
   constexpr int R = 16 * WAVES;
-  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * 4 + 16) +
+  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + 2 * cb16_w_bytes<CIN, COUT_PAD, NP>() +
                          (size_t)2 * R * sizeof(int2) + 16;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static_assert(((R + 1) * (COUT_PAD + 4) * 4) % 16 == 0 && (2 * COUT_PAD * (CIN * 4 + 16)) % 8 == 0, "LDS alignment");
-  auto kern = spconv_cb16<CIN, COUT_PAD, WAVES>;
+  static_assert(((R + 1) * (COUT_PAD + 4) * 4) % 16 == 0 && (2 * cb16_w_bytes<CIN, COUT_PAD, NP>()) % 16 == 0,
+                "LDS alignment");
+  auto kern = spconv_cb16<CIN, COUT_PAD, WAVES, NP>;
   if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
   dim3 grid((unsigned)n_tiles, (unsigned)vx_cdiv(a.cout, COUT_PAD));
   kern<<<grid, 64 * WAVES, lds, stream>>>(a, row_base, n_tiles, part);
@@ -1467,11 +1564,16 @@ int32_t launch_cb16_rows(const ConvArgs& a, long long row_base, long long n_tile
 
 // The kernel keeps one 256-row workgroup per CU, so G = cus * q + rem tiles cost q + 1 rounds however small rem is (one FHD
 // frame: 824 tiles at the 64-channel stage = 3.2 rounds, paid as 4). When the last partial round would fill at most half of
-// the CUs, its rows run as a second launch of the same kernel on 128-row tiles (8 waves, two workgroups per CU): about half
-// a round instead of a whole one. An output row's sum runs over the offsets in the same order whatever tile it sits in:
-// bitwise identical to the single launch (VX_CONV_NO_SPLIT_TAIL selects that one).
-template <int CIN, int COUT_PAD, int WAVES>
+// the CUs, its rows run as a second launch of the same kernel on 128-row tiles (8 waves; two workgroups per CU in the fp32
+// MFMA form, one in the split form whose W planes take more LDS): about half a round instead of a whole one. An output
+// row's sum runs over the offsets in the same order whatever tile it sits in: bitwise identical to the single launch
+// (VX_CONV_NO_SPLIT_TAIL selects that one).
+template <int CIN, int COUT_PAD, int WAVES, int NP = 0>
 int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
+  if constexpr (NP == 0) {
+    if (a.f32_products == 6) return launch_cb16<CIN, COUT_PAD, WAVES, 6>(a, stream);
+    if (a.f32_products == 9) return launch_cb16<CIN, COUT_PAD, WAVES, 9>(a, stream);
+  }
   constexpr int R = 16 * WAVES;
   const long long tiles = vx_cdiv(a.n_out, R);
   const int cus = a.cus;
@@ -1479,18 +1581,18 @@ int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
     // row count on the device: a.n_out is the capacity. Part 0 over every tile the capacity allows, part 1 (the
     // half-height tail, at most `cus` tiles) whenever the split rule could apply; the kernels take the same
     // decisions as below from the device count and surplus workgroups exit.
-    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles, 0, stream)) return rc;
+    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES, NP>(a, 0, tiles, 0, stream)) return rc;
     if (!a.no_split && a.cout <= COUT_PAD)
-      return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2>(a, 0, cus, 1, stream);
+      return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2, NP>(a, 0, cus, 1, stream);
     return VX_OK;
   }
   const long long rem = tiles % cus;
   if (!a.no_split && a.cout <= COUT_PAD && rem > 0 && 2 * rem <= cus && tiles > rem) {
-    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles - rem, 0, stream)) return rc;
+    if (int32_t rc = launch_cb16_rows<CIN, COUT_PAD, WAVES, NP>(a, 0, tiles - rem, 0, stream)) return rc;
     const long long base = (tiles - rem) * R;
-    return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2>(a, base, vx_cdiv(a.n_out - base, R / 2), 1, stream);
+    return launch_cb16_rows<CIN, COUT_PAD, WAVES / 2, NP>(a, base, vx_cdiv(a.n_out - base, R / 2), 1, stream);
   }
-  return launch_cb16_rows<CIN, COUT_PAD, WAVES>(a, 0, tiles, 0, stream);
+  return launch_cb16_rows<CIN, COUT_PAD, WAVES, NP>(a, 0, tiles, 0, stream);
 }
 
 template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1>
