@@ -104,6 +104,12 @@ def test_modes_strided_epilogue_and_dgrad(ks, st, pd, mode, dev):
     ref_din = so.conv_dgrad(dout, w, nbr, coords.shape[0])
     din = ops.conv_dgrad(torch.from_numpy(dout).to(dev), wd, rb).cpu().numpy()
     assert np.abs(din - ref_din).max() <= 1e-4 * np.abs(ref_din).max()
+    # weight gradient (reduction over the pairs, 16 per MFMA in the split forms): every mode against fp32 and fp64
+    ref_dw = so.conv_wgrad(feat, dout, nbr, w.shape)
+    ref_dw64 = so.conv_wgrad(feat, dout, nbr, w.shape, dtype=np.float64)
+    dw = ops.conv_wgrad(fd, torch.from_numpy(dout).to(dev), rb, w.shape).cpu().numpy()
+    assert np.abs(dw - ref_dw).max() <= 1e-4 * np.abs(ref_dw).max()
+    assert np.abs(dw - ref_dw64).max() <= 2e-5 * np.abs(ref_dw64).max()
     # submanifold dgrad (mirrored table)
     nbr_s = so.rulebook_subm(coords, shape, 3)
     ws = _wide(rng, (cin, 3, 3, 3, cin)) / np.float32(np.sqrt(27 * cin))
@@ -147,6 +153,34 @@ def test_split_forms_edge_sizes_tails_and_device_counts(n_sites, mode, dev):
     rb_d = ops_dn.rulebook_subm_dn(coords_c, counts, 2, shape, 3)
     out_d = ops_dn.conv_fwd_dn(feat_c, wd, rb_d, relu=True)
     assert torch.equal(out_d[:n], got)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128), (16, 32), (48, 64)])
+def test_wgrad_modes_vs_fp64(cin, cout, dev):
+    """weight gradient over a rulebook with uneven pair counts per offset (one chunk boundary inside): the split forms
+    are no further from the fp64 oracle than the fp32 MFMA; widths that do not fill 32-channel tiles keep the fp32 form."""
+    from oracle import spconv_oracle as so
+    from vista_amd import ops
+    rng = np.random.default_rng(cin + 7 * cout)
+    shape = [9, 60, 60]
+    coords = random_sites(rng, 2, shape, 9000)
+    n = coords.shape[0]
+    feat, dout = _wide(rng, (n, cin)), _wide(rng, (n, cout))
+    nbr = so.rulebook_subm(coords, shape, 3)
+    wshape = (cout, 3, 3, 3, cin)
+    ref64 = so.conv_wgrad(feat, dout, nbr, wshape, dtype=np.float64)
+    rb = ops.rulebook_subm(torch.from_numpy(coords).to(dev), 2, shape, 3)
+    fd, dd = torch.from_numpy(feat).to(dev), torch.from_numpy(dout).to(dev)
+    rms = {}
+    for mode in MODES:
+        ops.set_f32_products(mode)
+        dw = ops.conv_wgrad(fd, dd, rb, wshape)
+        assert torch.equal(dw, ops.conv_wgrad(fd, dd, rb, wshape))
+        e = dw.cpu().numpy().astype(np.float64) - ref64
+        assert np.abs(e).max() <= 2e-5 * np.abs(ref64).max(), mode
+        rms[mode] = np.sqrt((e ** 2).mean())
+    for mode in (6, 9):
+        assert rms[mode] <= 1.05 * rms[0], rms
 
 
 @pytest.mark.parametrize("mode", [0, 9])

@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "vx_common.h"
+#include "vx_split.h"
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -215,7 +216,6 @@ constexpr int kKSlots = 28;  // index-table rows kept in LDS (kvol <= 28)
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(256))) float vx_zero_row[128];  // zero-initialised, 512 B
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kW8Threads = 512;
 constexpr int kW8Rows = 256;
@@ -518,32 +518,6 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8_split_tail(ConvArgs a
 // staged as fp32 (pieces swizzled by (row >> 1) & 7) and split by the wave that owns them right after the
 // fragment read (each gathered value is read as a fragment exactly once: a wave covers all output columns).
 // ------------------------------------------------------------------------------------------------
-struct Planes {
-  bf16x8 h, m, l;
-};
-__device__ __forceinline__ unsigned top16(unsigned hi_word, unsigned lo_word) {  // {hi_word[31:16], lo_word[31:16]}
-  return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
-}
-__device__ __forceinline__ Planes split8(const f32x4& x0, const f32x4& x1) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 ph, pm, pl;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float xa = i < 2 ? x0[2 * i] : x1[2 * i - 4], xb = i < 2 ? x0[2 * i + 1] : x1[2 * i - 3];
-    const unsigned ua = __float_as_uint(xa), ub = __float_as_uint(xb);
-    ph[i] = top16(ub, ua);
-    const float ra = xa - __uint_as_float(ua & 0xffff0000u), rb = xb - __uint_as_float(ub & 0xffff0000u);
-    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-    pm[i] = top16(vb, va);
-    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
-    pl[i] = top16(__float_as_uint(sb), __float_as_uint(sa));
-  }
-  Planes p;
-  p.h = __builtin_bit_cast(bf16x8, ph);
-  p.m = __builtin_bit_cast(bf16x8, pm);
-  p.l = __builtin_bit_cast(bf16x8, pl);
-  return p;
-}
 #define VX_BF16_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 
 constexpr int kSChunk = 32;                    // fp32 values per chunk

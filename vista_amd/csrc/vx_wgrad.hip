@@ -14,6 +14,7 @@
 // fixed at Cout/4 flop per gathered byte, so where the bytes come from is what sets its speed).
 // Pass 2: per (k, co, ci) the slabs are summed in chunk order.
 #include "vx_common.h"
+#include "vx_split.h"
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -206,6 +207,151 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_partial(const float* __rest
     }
 }
 
+// The same pass on the bf16 matrix pipe (split arithmetic of spconv_w8s, vx_conv.hip): every fp32 operand is the exact
+// sum of three bf16 planes, NP plane products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulation. One
+// MFMA reduces over 16 pairs: lane (r, h) holds its channel of pairs {2 i + h, i = 0..7} of a 16-pair batch (eight
+// row loads, as many as the fp32 form spends on 16 pairs), splits the eight values of each of its channels and feeds
+// them as one k-group. A wave owns at most 2 x 2 tiles (the split costs VALU work per operand value, so operands
+// per MFMA is what to minimise: 32 values for 24 or 36 MFMAs); WM x WN waves tile Cout x Cin, PS = 4 / (WM WN) waves
+// share the pair range and are combined in a fixed order.
+template <int TM, int TN, bool VEC, int NP>
+__global__ __launch_bounds__(kThreads, 2) void wgrad_partial_s(const float* __restrict__ in, int cin,
+                                                            const float* __restrict__ dout, int cout,
+                                                            const int* __restrict__ pairs,
+                                                            const int* __restrict__ bounds,
+                                                            long long n_out, int nchunks, int kvol,
+                                                            float* __restrict__ slabs) {
+  static_assert(NP == 6 || NP == 9, "six or nine plane products");
+  constexpr int MW = TM >= 2 ? 2 : 1, NW = TN >= 2 ? 2 : 1;   // tiles per wave along Cout / Cin
+  constexpr int WM = TM / MW, WN = TN / NW;                   // waves along Cout / Cin
+  static_assert(WM * WN <= 4 && 4 % (WM * WN) == 0, "wave grid");
+  constexpr int PS = 4 / (WM * WN);
+  constexpr int B = 16;                                       // pairs per batch = one MFMA's reduction
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int k = (int)(wg % (unsigned)kvol), chunk = (int)(wg / (unsigned)kvol);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ps = wave / (WM * WN), wm = (wave % (WM * WN)) / WN, wn = wave % WN;
+  const int* pin = pairs + (long long)k * 2 * n_out;
+  const int* pout = pin + n_out;
+  const int p_lo = bounds[k * (nchunks + 1) + chunk], p_hi = bounds[k * (nchunks + 1) + chunk + 1];
+  const int sub = (p_hi - p_lo + PS - 1) / PS;
+  const int p_begin = p_lo + ps * sub;
+  int p_end = p_begin + sub;
+  if (p_end > p_hi) p_end = p_hi;
+  const int nb = p_end > p_begin ? (p_end - p_begin + B - 1) / B : 0;
+
+  const int a_c0 = TM * r + wm * MW, b_c0 = TN * r + wn * NW;
+
+  f32x16 acc[MW][NW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m)
+#pragma unroll
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+
+  auto load_ids = [&](int bt, int& li, int& lo) {     // lane l < 16 holds pair (batch start + l); -1 past the end
+    const int p = p_begin + bt * B + lane;
+    li = lo = -1;
+    if (bt < nb && lane < B && p < p_end) {
+      li = pin[p];
+      lo = pout[p];
+    }
+  };
+  auto fetch = [&](int li, int lo, Vec<MW>(&av)[8], Vec<NW>(&bv)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ii = __shfl(li, 2 * u + h, 64), oo = __shfl(lo, 2 * u + h, 64);
+      av[u] = load_channels<MW, VEC>(dout, oo, cout, a_c0);
+      bv[u] = load_channels<NW, VEC>(in, ii, cin, b_c0);
+    }
+  };
+  auto mma = [&](const Vec<MW>(&av)[8], const Vec<NW>(&bv)[8]) {
+    Planes A[MW], Bp[NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      const float x[8] = {av[0].v[m], av[1].v[m], av[2].v[m], av[3].v[m], av[4].v[m], av[5].v[m], av[6].v[m], av[7].v[m]};
+      A[m] = split8s(x);
+    }
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      const float x[8] = {bv[0].v[n], bv[1].v[n], bv[2].v[n], bv[3].v[n], bv[4].v[n], bv[5].v[n], bv[6].v[n], bv[7].v[n]};
+      Bp[n] = split8s(x);
+    }
+#define VX_WMMA(PA, PB)                                                                              \
+  _Pragma("unroll") for (int m = 0; m < MW; ++m) _Pragma("unroll") for (int n = 0; n < NW; ++n)      \
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m].PA, Bp[n].PB, acc[m][n], 0, 0, 0)
+    if constexpr (NP == 9) {
+      VX_WMMA(l, l);
+      VX_WMMA(m, l);
+      VX_WMMA(l, m);
+    }
+    VX_WMMA(m, m);
+    VX_WMMA(h, l);
+    VX_WMMA(l, h);
+    VX_WMMA(h, m);
+    VX_WMMA(m, h);
+    VX_WMMA(h, h);
+#undef VX_WMMA
+  };
+
+  Vec<MW> a0[8], a1[8];
+  Vec<NW> b0[8], b1[8];
+  int li0, lo0, li1, lo1;
+  load_ids(0, li0, lo0);
+  load_ids(1, li1, lo1);
+  fetch(li0, lo0, a0, b0);
+  for (int bt = 0; bt < nb; bt += 2) {
+    load_ids(bt + 2, li0, lo0);
+    fetch(li1, lo1, a1, b1);
+    mma(a0, b0);
+    load_ids(bt + 3, li1, lo1);
+    fetch(li0, lo0, a0, b0);
+    mma(a1, b1);
+  }
+
+  constexpr int WT = MW * NW * 16 * 64;              // floats of one wave's accumulators
+  __shared__ float part[PS > 1 ? (PS - 1) * WM * WN * WT : 1];
+  static_assert(sizeof(part) <= 64 * 1024, "static LDS");
+  if constexpr (PS > 1) {
+    if (ps > 0) {
+      float* dst = part + ((ps - 1) * WM * WN + wm * WN + wn) * WT + lane;
+#pragma unroll
+      for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[((m * NW + n) * 16 + i) * 64] = acc[m][n][i];
+    }
+    __syncthreads();
+    if (ps > 0) return;
+#pragma unroll 1
+    for (int q = 0; q < PS - 1; ++q) {
+      const float* src = part + (q * WM * WN + wm * WN + wn) * WT + lane;
+#pragma unroll
+      for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] += src[((m * NW + n) * 16 + i) * 64];
+    }
+  }
+  float* slab = slabs + ((long long)chunk * kvol + k) * (long long)cout * cin;
+#pragma unroll
+  for (int m = 0; m < MW; ++m)
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      const int ci = b_c0 + n;
+      if (ci >= cin) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = TM * ((i & 3) + 8 * (i >> 2) + 4 * h) + wm * MW + m;
+        if (co < cout) slab[(long long)co * cin + ci] = acc[m][n][i];
+      }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void wgrad_reduce(const float* __restrict__ slabs, int nchunks,
                                                          int cout, int cin, int kvol,
                                                          float* __restrict__ dw) {
@@ -219,10 +365,30 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce(const float* __restrict
   dw[((long long)co * kvol + k) * cin + ci] = sum;
 }
 
+template <int TM, int TN, int NP>
+void launch_partial_s(const float* in, int cin, const float* dout, int cout, const int* pairs,
+                      const int* bounds, long long n_out, int nchunks, int kvol, float* slabs,
+                      hipStream_t stream) {
+  constexpr int MW = TM >= 2 ? 2 : 1, NW = TN >= 2 ? 2 : 1;      // as in the kernel
+  const dim3 grid((unsigned)(nchunks * kvol));
+  if (cout % TM == 0 && cin % TN == 0 && cout % MW == 0 && cin % NW == 0)
+    wgrad_partial_s<TM, TN, true, NP><<<grid, kThreads, 0, stream>>>(in, cin, dout, cout, pairs, bounds, n_out,
+                                                                     nchunks, kvol, slabs);
+  else
+    wgrad_partial_s<TM, TN, false, NP><<<grid, kThreads, 0, stream>>>(in, cin, dout, cout, pairs, bounds, n_out,
+                                                                      nchunks, kvol, slabs);
+}
+
 template <int TM, int TN>
 void launch_partial(const float* in, int cin, const float* dout, int cout, const int* pairs,
                     const int* bounds, long long n_out, int nchunks, int kvol, float* slabs,
-                    hipStream_t stream) {
+                    hipStream_t stream, int products) {
+  // split arithmetic where the channels fill the MFMA tiles (the fp32 form keeps the ragged widths)
+  if (products && cout % 32 == 0 && cin % 32 == 0) {
+    if (products == 6)
+      return launch_partial_s<TM, TN, 6>(in, cin, dout, cout, pairs, bounds, n_out, nchunks, kvol, slabs, stream);
+    return launch_partial_s<TM, TN, 9>(in, cin, dout, cout, pairs, bounds, n_out, nchunks, kvol, slabs, stream);
+  }
   constexpr int NT = TN / ((TN >= 2 && TM * TN >= 8) ? 2 : 1);   // as in the kernel
   const dim3 grid((unsigned)(nchunks * kvol));
   if (cout % TM == 0 && cin % NT == 0)
@@ -233,6 +399,8 @@ void launch_partial(const float* in, int cin, const float* dout, int cout, const
                                                                 nchunks, kvol, slabs);
 }
 }  // namespace
+
+extern "C" int32_t vx_spconv_get_f32_products(void);   // vx_conv.hip: the process-wide fp32 matrix arithmetic
 
 extern "C" size_t vx_spconv_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t kvol,
                                                   int64_t n_out) {
@@ -267,6 +435,7 @@ extern "C" int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, 
   if (tm == 3) tm = 4;
   if (tn == 3) tn = 4;
   VX_REQUIRE(n_out < (1ll << 31) && n_in < (1ll << 31), "spconv_wgrad: row ids must fit int32");
+  const int products = vx_spconv_get_f32_products();
   const int nchunks = (int)vx_cdiv(n_out, kChunkRows);
   const float* in = (const float*)d_in;
   const float* dout = (const float*)d_dout;
@@ -278,7 +447,7 @@ extern "C" int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, 
 #define VX_WG(TM, TN)                                                                          \
   if (tm == TM && tn == TN)                                                                    \
     launch_partial<TM, TN>(in, cin, dout, cout, d_pairs, bounds, n_out, nchunks, kvol, slabs,      \
-                           stream);
+                           stream, products);
   VX_WG(1, 1) VX_WG(1, 2) VX_WG(1, 4)
   VX_WG(2, 1) VX_WG(2, 2) VX_WG(2, 4)
   VX_WG(4, 1) VX_WG(4, 2) VX_WG(4, 4)
