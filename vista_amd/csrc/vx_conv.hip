@@ -191,11 +191,8 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 }
 
 
-#ifndef VX_ABL
-#define VX_ABL 0
-#endif
-#ifndef VX_W8S_WMID
-#define VX_W8S_WMID 1
+#ifndef VX_W8S_S16
+#define VX_W8S_S16 1   // MFMA shape of spconv_w8s: 1 = 16x16x32, 0 = 32x32x16
 #endif
 #ifndef VX_F32_PRODUCTS_DEFAULT
 #define VX_F32_PRODUCTS_DEFAULT 6
@@ -579,11 +576,23 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
 #pragma unroll
   for (int i = 0; i < NW; ++i) gmask |= (unsigned)sMask[i];
 
-  f32x16 acc[NT];
+  // accumulators: S16 = v_mfma_f32_16x16x32_bf16 (2 row tiles x COUT_PAD/16 column tiles of 16 x 16, one MFMA per
+  // chunk and plane product), else v_mfma_f32_32x32x16_bf16 (COUT_PAD/32 tiles of 32 x 32, two MFMAs per chunk)
+  constexpr bool S16 = VX_W8S_S16 != 0;
+  constexpr int CT = COUT_PAD / 16;
+  f32x16 acc[S16 ? 1 : NT];
+  f32x4 acc16[S16 ? 2 : 1][S16 ? CT : 1];
+  if constexpr (S16) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+      for (int ct = 0; ct < CT; ++ct) acc16[rt][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+  }
 
   auto chunk_used = [&](unsigned m, int c) { return ((m >> (c / (CIN / kSChunk))) & 1u) != 0u; };
   auto next_chunk = [&](int c) {
@@ -601,16 +610,8 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
     for (int t = 0; t < 4; ++t) {
       const int row = 8 * t + arow;
       const int idx = sIdx[g * 32 + row];
-#if VX_ABL == 1 || VX_ABL == 6   // timing-only builds (results wrong by construction): no gathers
-      ra[t] = f32x4{(float)idx, (float)ch, 0.f, 0.f};
-#elif VX_ABL == 5  // gathers from the zero row only
-      ra[t] = *reinterpret_cast<const f32x4*>(zero + (idx & 3));
-#elif VX_ABL == 8  // gathers from the tile's own rows (sequential addresses)
-      ra[t] = *reinterpret_cast<const f32x4*>(in + (row0 + row + (idx & 1)) * CIN + ch);
-#else
       const float* src = idx >= 0 ? in + (long long)idx * CIN + ch : zero;
       ra[t] = *reinterpret_cast<const f32x4*>(src);
-#endif
     }
   };
   auto store_a = [&](int buf) {
@@ -629,20 +630,9 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
       const int woc = ((int)threadIdx.x + i * NTHR) >> 2;
       const int goc = col0 + woc;
       const bool ok = woc < COUT_PAD && goc < a.cout;
-#if VX_ABL == 9   // chunk-major W image (timing only: reads the wrong elements)
-      const float* src = ok ? wgt + (long long)c * (COUT_PAD * kSChunk) + woc * kSChunk + 8 * wq : zero;
-      (void)g; (void)ch;
-#else
       const float* src = ok ? wgt + ((long long)goc * a.kvol + g) * CIN + ch : zero;
-#endif
-#if VX_ABL == 2 || VX_ABL == 6   // no W loads
-      rw[2 * i] = f32x4{(float)g, (float)ch, 1.f, 0.f};
-      rw[2 * i + 1] = rw[2 * i];
-      (void)src;
-#else
       rw[2 * i] = *reinterpret_cast<const f32x4*>(src);
       rw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
-#endif
     }
   };
   auto store_w = [&](int buf) {
@@ -657,51 +647,87 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
       *reinterpret_cast<bf16x8*>(dst + 2 * COUT_PAD * kSPlaneRow) = p.l;
     }
   };
-  auto mfma_steps = [&](int buf, auto s_begin, auto s_end) {
-    const char* pa = sA + buf * ABUF + r * kSRowBytes;
-    const char* pb = smem_raw + buf * WBUF + r * kSPlaneRow;
-    const int ka = (r >> 1) & 7, kb = (r >> 2) & 3;
+  const int n16 = lane & 15, kg = lane >> 4;
+  auto mfma_chunk = [&](int buf) {
+    if constexpr (S16) {
+      // lane (n16, kg): values [8 kg, 8 kg + 8) of the chunk = pieces 2 kg, 2 kg + 1 of gathered row 16 rt + n16, piece kg
+      // of W row 16 ct + n16 in each plane image
+      Planes A[2];
 #pragma unroll
-    for (int s = decltype(s_begin)::value; s < decltype(s_end)::value; ++s) {
-      const int q = 4 * s + 2 * h;
-#if VX_ABL == 4   // no split of the gathered fragments
-      Planes A;
-      A.h = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(pa + ((q ^ ka) << 4)));
-      A.m = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(pa + (((q + 1) ^ ka) << 4)));
-      A.l = A.h;
-#else
-      const Planes A = split8(*reinterpret_cast<const f32x4*>(pa + ((q ^ ka) << 4)),
-                              *reinterpret_cast<const f32x4*>(pa + (((q + 1) ^ ka) << 4)));
-#endif
-      const int ob = ((2 * s + h) ^ kb) << 4;
-      bf16x8 Bh[NT], Bm[NT], Bl[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        Bh[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * kSPlaneRow + ob);
-        Bm[t] = *reinterpret_cast<const bf16x8*>(pb + COUT_PAD * kSPlaneRow + t * 32 * kSPlaneRow + ob);
-        Bl[t] = *reinterpret_cast<const bf16x8*>(pb + 2 * COUT_PAD * kSPlaneRow + t * 32 * kSPlaneRow + ob);
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = 16 * rt + n16, ka = (row >> 1) & 7;
+        const char* pa = sA + buf * ABUF + row * kSRowBytes;
+        A[rt] = split8(*reinterpret_cast<const f32x4*>(pa + (((2 * kg) ^ ka) << 4)),
+                       *reinterpret_cast<const f32x4*>(pa + (((2 * kg + 1) ^ ka) << 4)));
       }
-      // smallest products first, h*h last
-      if constexpr (NP == 9) {
+      const char* pb = smem_raw + buf * WBUF + n16 * kSPlaneRow + ((kg ^ ((n16 >> 2) & 3)) << 4);
+#define VX_MMA16(PA, B_) acc16[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt].PA, B_, acc16[rt][ct], 0, 0, 0)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bl[t], acc[t]);
+      for (int ct = 0; ct < CT; ++ct) {
+        const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(pb + ct * 16 * kSPlaneRow);
+        const bf16x8 Bm = *reinterpret_cast<const bf16x8*>(pb + COUT_PAD * kSPlaneRow + ct * 16 * kSPlaneRow);
+        const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(pb + 2 * COUT_PAD * kSPlaneRow + ct * 16 * kSPlaneRow);
+        if constexpr (NP == 9) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bl[t], acc[t]);
+          for (int rt = 0; rt < 2; ++rt) VX_MMA16(l, Bl);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bm[t], acc[t]);
+          for (int rt = 0; rt < 2; ++rt) VX_MMA16(m, Bl);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) VX_MMA16(l, Bm);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) VX_MMA16(m, Bm);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) VX_MMA16(h, Bl);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) VX_MMA16(l, Bh);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) VX_MMA16(h, Bm);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) VX_MMA16(m, Bh);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) VX_MMA16(h, Bh);
       }
+#undef VX_MMA16
+    } else {
+      const char* pa = sA + buf * ABUF + r * kSRowBytes;
+      const char* pb = smem_raw + buf * WBUF + r * kSPlaneRow;
+      const int ka = (r >> 1) & 7, kb = (r >> 2) & 3;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bm[t], acc[t]);
+      for (int s = 0; s < 2; ++s) {
+        const int q = 4 * s + 2 * h;
+        const Planes A = split8(*reinterpret_cast<const f32x4*>(pa + ((q ^ ka) << 4)),
+                                *reinterpret_cast<const f32x4*>(pa + (((q + 1) ^ ka) << 4)));
+        const int ob = ((2 * s + h) ^ kb) << 4;
+        bf16x8 Bh[NT], Bm[NT], Bl[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bl[t], acc[t]);
+        for (int t = 0; t < NT; ++t) {
+          Bh[t] = *reinterpret_cast<const bf16x8*>(pb + t * 32 * kSPlaneRow + ob);
+          Bm[t] = *reinterpret_cast<const bf16x8*>(pb + COUT_PAD * kSPlaneRow + t * 32 * kSPlaneRow + ob);
+          Bl[t] = *reinterpret_cast<const bf16x8*>(pb + 2 * COUT_PAD * kSPlaneRow + t * 32 * kSPlaneRow + ob);
+        }
+        // smallest products first, h*h last
+        if constexpr (NP == 9) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bh[t], acc[t]);
+          for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bl[t], acc[t]);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bm[t], acc[t]);
+          for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bl[t], acc[t]);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bh[t], acc[t]);
+          for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bm[t], acc[t]);
+        }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bh[t], acc[t]);
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bm[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bl[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.l, Bh[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bm[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.m, Bh[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) VX_BF16_MMA(A.h, Bh[t], acc[t]);
+      }
     }
   };
 
@@ -724,32 +750,14 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
     load_a(cl);
   }
   __syncthreads();
-  // The two waves of a SIMD (w and w + NW/2) take the two halves of a trip in opposite order, so that one stages and
-  // issues loads while the other feeds the matrix pipe.
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
   while (c < nchunks) {
     const int cnn = cn < nchunks ? next_chunk(cn) : cn;
     const int cl = cnn < nchunks ? cnn : c;
-    const bool used = chunk_used(wmask, c);
     store_a(buf ^ 1);
     store_w(buf ^ 1);
-#if VX_W8S_WMID   // the W loads go out between the two MFMA steps, the gathers before the first
-    load_a(cl);
-    __builtin_amdgcn_sched_barrier(0);
-    if (used) mfma_steps(buf, I0{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(cl);
-    __builtin_amdgcn_sched_barrier(0);
-    if (used) mfma_steps(buf, I1{}, I2{});
-#else
     load_w(cl);
     load_a(cl);
-#if VX_ABL != 3   // 3: no MFMA stream
-    if (used) mfma_steps(buf, I0{}, I2{});
-#endif
-#endif
+    if (chunk_used(wmask, c)) mfma_chunk(buf);
     __syncthreads();
     buf ^= 1;
     c = cn;
@@ -759,23 +767,38 @@ __device__ __forceinline__ void w8s_body(const ConvArgs& a, const long long n_ou
   // ---- epilogue: bias, per-channel affine (folded BatchNorm), residual, ReLU ---------------------
   float* out = a.out;
   const float* res = a.residual;
+  auto emit = [&](long long row, int col, float acc_v, float b, float sc, float sh) {
+    if (row >= n_out) return;
+    const long long orow = a.perm ? a.perm[row] : row;
+    float v = acc_v + b;
+    if (a.scale || a.shift) v = v * sc + sh;
+    if (res) v += res[orow * a.cout + col];
+    if (a.relu) v = fmaxf(v, 0.0f);
+    out[orow * a.cout + col] = v;
+  };
+  if constexpr (S16) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = col0 + t * 32 + r;
-    if (col >= a.cout) continue;
-    const float b = a.bias ? a.bias[col] : 0.0f;
-    const float sc = a.scale ? a.scale[col] : 1.0f;
-    const float sh = a.shift ? a.shift[col] : 0.0f;
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = col0 + ct * 16 + n16;
+      if (col >= a.cout) continue;
+      const float b = a.bias ? a.bias[col] : 0.0f;
+      const float sc = a.scale ? a.scale[col] : 1.0f;
+      const float sh = a.shift ? a.shift[col] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= n_out) continue;
-      const long long orow = a.perm ? a.perm[row] : row;
-      float v = acc[t][i] + b;
-      if (a.scale || a.shift) v = v * sc + sh;
-      if (res) v += res[orow * a.cout + col];
-      if (a.relu) v = fmaxf(v, 0.0f);
-      out[orow * a.cout + col] = v;
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) emit(row0 + 16 * rt + 4 * kg + i, col, acc16[rt][ct][i], b, sc, sh);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = col0 + t * 32 + r;
+      if (col >= a.cout) continue;
+      const float b = a.bias ? a.bias[col] : 0.0f;
+      const float sc = a.scale ? a.scale[col] : 1.0f;
+      const float sh = a.shift ? a.shift[col] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) emit(row0 + (i & 3) + 8 * (i >> 2) + 4 * h, col, acc[t][i], b, sc, sh);
     }
   }
 }

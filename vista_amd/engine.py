@@ -108,9 +108,11 @@ def _run(steps, st, geom_only=False):
     return st
 
 
-def _run_dn(steps, st, caps, counts, slot, err, geom_only=False):
+def _run_dn(steps, st, caps, counts, slot, err, geom_only=False, mark=None):
     """_run with device-resident row counts (vista_amd.ops_dn): no host sync anywhere. `caps[j]` / `counts[slot + j]`
-    = output capacity / count slot of the j-th strided conv met (in call order over the whole plan)."""
+    = output capacity / count slot of the j-th strided conv met (in call order over the whole plan).
+    geom_only: build the rulebooks only (they depend on coordinates alone); `mark(rb)` is called on every rulebook
+    built, and a rulebook that carries a `ready` event (built on another stream) is waited for before its first use."""
     from . import ops_dn
     st = _State(st.feat, st.idx, st.shape, st.batch, st.cache, st.rank)
     st.n = st.cache["n", id(st.idx)]
@@ -122,6 +124,8 @@ def _run_dn(steps, st, caps, counts, slot, err, geom_only=False):
             if rb is None:
                 rb = ops_dn.rulebook_subm_dn(st.idx, st.n, st.batch, st.shape, s.ksize, rank=st.rank)
                 st.cache[key] = rb
+                if mark is not None:
+                    mark(rb)
         else:
             key = ("conv", id(st.idx), tuple(s.ksize), tuple(s.stride), tuple(s.padding))
             rb = st.cache.get(key)
@@ -132,6 +136,11 @@ def _run_dn(steps, st, caps, counts, slot, err, geom_only=False):
                                              caps[j], counts[slot + j:slot + j + 1], err)
                 st.cache[key] = rb
                 st.cache["n", id(rb.out_indices)] = rb.n_out
+                if mark is not None:
+                    mark(rb)
+        if not geom_only and getattr(rb, "ready", None) is not None:
+            torch.cuda.current_stream(st.idx.device).wait_event(rb.ready)
+            rb.ready = None
         if s.residual == "save":
             identity = st.feat
         res = identity if s.residual == "add" else None
@@ -178,6 +187,26 @@ class FramePlan:
         self.graph = None
         self.out = None
         self.limit = None          # diagnostic (tools/graph_probe.py): stop after this many steps of the middle stack
+        # Rulebooks depend on coordinates only: they are built on a second stream (a parallel branch of the captured
+        # graph) while the first stage's convolutions run, each handed over through an event. Same kernels on the same
+        # inputs: outputs are unchanged. VX_GEOM_OVERLAP=0 keeps everything on one stream.
+        self.geom_stream = torch.cuda.Stream(dev) if os.environ.get("VX_GEOM_OVERLAP", "1") != "0" else None
+
+    def _geometry_ahead(self, st, args):
+        """All rulebooks of the plan on the geometry stream, in the order the feature pass meets them."""
+        e = self.engine
+        main = torch.cuda.current_stream(self.dev)
+        side = self.geom_stream
+        side.wait_stream(main)                     # after the voxelizer
+
+        def mark(rb):
+            rb.ready = torch.cuda.Event()
+            rb.ready.record(side)
+        with torch.cuda.stream(side):
+            mid = _run_dn(e.middle, st, *args, geom_only=True, mark=mark)
+            if e.kind != "SpMiddleResNetFHD":
+                _run_dn(e.bev, mid, *args, geom_only=True, mark=mark)
+                _run_dn(e.rv, mid, *args, geom_only=True, mark=mark)
 
     def _forward(self):
         from . import ops_dn
@@ -193,6 +222,16 @@ class FramePlan:
         if self.limit is not None:
             mid = _run_dn(e.middle[:self.limit], st, *args)
             return mid.feat, mid.idx
+        if self.geom_stream is not None:
+            self._geometry_ahead(st, args)
+        try:
+            return self._features(st, args, od)
+        finally:
+            if self.geom_stream is not None:       # join (every rulebook was waited for; this closes the branch)
+                torch.cuda.current_stream(self.dev).wait_stream(self.geom_stream)
+
+    def _features(self, st, args, od):
+        e = self.engine
         mid = _run_dn(e.middle, st, *args)
         if e.kind == "SpMiddleResNetFHD":
             d = od.to_dense_dn(mid.feat, mid.idx, mid.n, mid.batch, mid.shape)
