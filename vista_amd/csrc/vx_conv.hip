@@ -191,6 +191,9 @@ __global__ __launch_bounds__(kThreads) void spconv_f32_generic(ConvArgs a) {
 }
 
 
+#ifndef VX_CB_SPLIT
+#define VX_CB_SPLIT 1   // split-bf16 arithmetic in the 32-pair compaction kernel (fp32 layers with Cin 16 / 32 / 64)
+#endif
 #ifndef VX_W8S_S16
 #define VX_W8S_S16 1   // MFMA shape of spconv_w8s: 1 = 16x16x32, 0 = 32x32x16
 #endif
@@ -1030,9 +1033,22 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
 #endif
 
 // NS waves share one 32-pair group, each taking Cout/NS of its output channels (more, lighter waves per tile).
-template <typename T, int CIN, int COUT_PAD, int WAVES, int NS>
+// NP = 6 / 9 (fp32 only): the split-bf16 arithmetic of spconv_w8s -- W_k split once per workgroup into three bf16 plane
+// images [Cout][CIN * 2 + 16 B], the gathered half rows split by their lane, v_mfma_f32_32x32x16_bf16 (lane (r, h) feeds
+// its channels [h CIN/2 + 8 s, + 8) to MFMA s as k-group h).
+template <typename T, int CIN, int COUT_PAD, int NP>
+constexpr size_t cb_w_bytes() {   // one W buffer
+  return NP ? (size_t)3 * COUT_PAD * (CIN * 2 + 16) : (size_t)COUT_PAD * (CIN * sizeof(T) + 16);
+}
+
+template <typename T, int CIN, int COUT_PAD, int WAVES, int NS, int NP = 0>
 __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(ConvArgs a) {
   constexpr int kCbRows = 32 * WAVES / NS, kCbThreads = 64 * WAVES;
+  static_assert(NP == 0 || (sizeof(T) == 4 && (NP == 6 || NP == 9) && CIN % 16 == 0), "split form: fp32, Cin % 16 == 0");
+  constexpr int P_ROW = CIN * 2 + 16, P_PLANE = COUT_PAD * P_ROW;
+  constexpr int W_BUF = (int)cb_w_bytes<T, CIN, COUT_PAD, NP>();
+  constexpr int W_P8 = COUT_PAD * CIN / 8;                                 // 8-value pieces of W_k (split form)
+  constexpr int W_PL = (W_P8 + kCbThreads - 1) / kCbThreads;
   static_assert(kCbRows % 64 == 0 && (COUT_PAD / 32) % NS == 0, "tile shape");
   constexpr int NE = kCbRows / 64;                   // neighbour entries per lane
   constexpr int NT = COUT_PAD / 32 / NS;             // 32-channel tiles per wave
@@ -1099,26 +1115,53 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
 #pragma unroll
     for (int q = 0; q < QH; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + 16 * q);
   };
-  f32x4 rw[W_LD];
+  f32x4 rw[NP ? 2 * W_PL : W_LD];
   auto load_w = [&](int ks) {
     const int kk = ks < a.kvol ? ks : a.kvol - 1;
+    if constexpr (NP != 0) {
 #pragma unroll
-    for (int t = 0; t < W_LD; ++t) {
-      const int e = t * kCbThreads + (int)threadIdx.x;
-      const int oc = e / QR, q = e % QR;
-      const int goc = col0 + oc;
-      const bool ok = e < W_Q && goc < a.cout;
-      const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * EB + 16 * q : zero;
-      rw[t] = *reinterpret_cast<const f32x4*>(src);
+      for (int t = 0; t < W_PL; ++t) {
+        const int e = t * kCbThreads + (int)threadIdx.x;
+        const int oc = e / (CIN / 8), p8 = e % (CIN / 8);
+        const int goc = col0 + oc;
+        const bool ok = e < W_P8 && goc < a.cout;
+        const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * 4 + 32 * p8 : zero;
+        rw[2 * t] = *reinterpret_cast<const f32x4*>(src);
+        rw[2 * t + 1] = *reinterpret_cast<const f32x4*>(src + 16);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < W_LD; ++t) {
+        const int e = t * kCbThreads + (int)threadIdx.x;
+        const int oc = e / QR, q = e % QR;
+        const int goc = col0 + oc;
+        const bool ok = e < W_Q && goc < a.cout;
+        const char* src = ok ? wgt + ((long long)goc * a.kvol + kk) * CIN * EB + 16 * q : zero;
+        rw[t] = *reinterpret_cast<const f32x4*>(src);
+      }
     }
   };
   auto store_w = [&](int buf) {
-    char* sW = sWb + buf * COUT_PAD * W_ROW;
+    char* sW = sWb + buf * W_BUF;
+    if constexpr (NP != 0) {
 #pragma unroll
-    for (int t = 0; t < W_LD; ++t) {
-      const int e = t * kCbThreads + (int)threadIdx.x;
-      const int oc = e / QR, q = e % QR;
-      if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
+      for (int t = 0; t < W_PL; ++t) {
+        const int e = t * kCbThreads + (int)threadIdx.x;
+        if (e >= W_P8) continue;
+        const int oc = e / (CIN / 8), p8 = e % (CIN / 8);
+        const Planes p = split8(rw[2 * t], rw[2 * t + 1]);
+        char* dst = sW + oc * P_ROW + 16 * p8;
+        *reinterpret_cast<bf16x8*>(dst) = p.h;
+        *reinterpret_cast<bf16x8*>(dst + P_PLANE) = p.m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * P_PLANE) = p.l;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < W_LD; ++t) {
+        const int e = t * kCbThreads + (int)threadIdx.x;
+        const int oc = e / QR, q = e % QR;
+        if (e < W_Q) *reinterpret_cast<f32x4*>(sW + oc * W_ROW + q * 16) = rw[t];
+      }
     }
   };
   // 32 pairs x Cout, computed TRANSPOSED (W fragment as the A operand, gathered rows as B): lane (r, h) then
@@ -1130,9 +1173,37 @@ __global__ __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) void spconv_cb(Conv
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) d[t][i] = 0.0f;
-    const char* pb = sWb + buf * COUT_PAD * W_ROW + (t0 * 32 + r) * W_ROW + h * (CIN * EB / 2);
+    if constexpr (NP != 0) {
+      static_assert(NP == 0 || QH % 2 == 0, "whole 8-value k-groups per lane");
+      const char* pw = sWb + buf * W_BUF + (t0 * 32 + r) * P_ROW + h * CIN;   // h * (CIN / 2) bf16 values
 #pragma unroll
-    for (int j = 0; j < QH; ++j) {
+      for (int s2 = 0; s2 < QH / 2; ++s2) {
+        const Planes g = split8(ra[2 * s2], ra[2 * s2 + 1]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const char* q0 = pw + t * 32 * P_ROW + 16 * s2;
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(q0);
+          const bf16x8 wm = *reinterpret_cast<const bf16x8*>(q0 + P_PLANE);
+          const bf16x8 wl = *reinterpret_cast<const bf16x8*>(q0 + 2 * P_PLANE);
+#define VX_MMA32(A, B) d[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, d[t], 0, 0, 0)
+          if constexpr (NP == 9) {
+            VX_MMA32(wl, g.l);
+            VX_MMA32(wm, g.l);
+            VX_MMA32(wl, g.m);
+          }
+          VX_MMA32(wm, g.m);
+          VX_MMA32(wh, g.l);
+          VX_MMA32(wl, g.h);
+          VX_MMA32(wh, g.m);
+          VX_MMA32(wm, g.h);
+          VX_MMA32(wh, g.h);
+#undef VX_MMA32
+        }
+      }
+    }
+    const char* pb = sWb + buf * W_BUF + (t0 * 32 + r) * W_ROW + h * (CIN * EB / 2);
+#pragma unroll
+    for (int j = 0; j < (NP ? 0 : QH); ++j) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + t * 32 * W_ROW + 16 * j);
@@ -1592,12 +1663,19 @@ int32_t launch_cb16(const ConvArgs& a, hipStream_t stream) {
   return launch_cb16_rows<CIN, COUT_PAD, WAVES, NP>(a, 0, tiles, 0, stream);
 }
 
-template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1>
+template <typename T, int CIN, int COUT_PAD, int WAVES, int NS = 1, int NP = 0>
 int32_t launch_cb(const ConvArgs& a, hipStream_t stream) {
+  // measured on the FHD layers (tools/conv_probe.py 8): SubM 32->32 1.04 -> 0.96 ms; the strided 16->32 / 32->64 layers lose
+  // 5-8 % (few pairs per tile and offset: splitting W_k for every offset costs more than the shorter MFMAs give back) and
+  // 16->16 ties, so only the 32 x 32 form takes the split arithmetic here
+  if constexpr (NP == 0 && sizeof(T) == 4 && CIN == 32 && COUT_PAD == 32 && VX_CB_SPLIT) {
+    if (a.f32_products == 6) return launch_cb<T, CIN, COUT_PAD, WAVES, NS, 6>(a, stream);
+    if (a.f32_products == 9) return launch_cb<T, CIN, COUT_PAD, WAVES, NS, 9>(a, stream);
+  }
   constexpr int R = 32 * WAVES / NS;
-  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + (size_t)2 * COUT_PAD * (CIN * sizeof(T) + 16);
+  constexpr size_t lds = (size_t)(R + 1) * (COUT_PAD + 4) * 4 + 2 * cb_w_bytes<T, CIN, COUT_PAD, NP>();
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = spconv_cb<T, CIN, COUT_PAD, WAVES, NS>;
+  auto kern = spconv_cb<T, CIN, COUT_PAD, WAVES, NS, NP>;
   if (int32_t rc = set_lds_once((const void*)kern, lds)) return rc;
   dim3 grid((unsigned)vx_cdiv(a.n_out, R), (unsigned)vx_cdiv(a.cout, COUT_PAD));
   kern<<<grid, 64 * WAVES, lds, stream>>>(a);
