@@ -493,6 +493,12 @@ def main():
                 v["bf16_batch8"] = infer_variant(a, dev, rank, "bf16", "FHD", a.batch, a.steps, want_roofline=True)
                 v["bf16_batch1"] = infer_variant(a, dev, rank, "bf16", "FHD", 1, st)
                 v["stress_batch1"] = infer_variant(a, dev, rank, "fp32", "STRESS", 1, 5, want_phases=True)
+                # configs[2] on one GPU: the full VISTA net (two-branch sparse backbone + dense tail), batch 4
+                av = parse(["--geometry", "VISTA", "--backbone", "MultiViewBackbone", "--full-net", "--batch", "4",
+                            "--steps", str(a.steps), "--warmup", "3"])
+                rv, _ = run_infer(av, dev, 0, 1, None, None, lambda: None)
+                v["vista_fullnet_batch4"] = {"frames_per_s": rv["value"], "ms_per_step": rv["ms_per_step"],
+                                             "metric": rv["metric"]}
                 from vista_amd.train import bench_train
                 at = parse(["--mode", "train", "--steps", "4", "--warmup", "2"])
                 tr = bench_train(at, dev, rank, 1, None)
