@@ -157,6 +157,17 @@ def test_sync_free_plan_equals_eager_path_bitwise(kind, geometry, dtype, dispatc
             assert g.shape == r.shape and g.dtype == r.dtype
             assert torch.equal(_bits(g), _bits(r))
     assert len(eng._plans) == 2 and len(builds) == 2   # batch 2 (built once, re-used for the second pair) and batch 1
+    if dtype == torch.float32 and kind == "SpMiddleResNetFHD":
+        # another fp32 matrix arithmetic is another plan (a captured graph keeps the kernels it recorded)
+        from vista_amd import ops
+        old = ops.set_f32_products(0)
+        try:
+            fr = _frames(dev, [3], 10)
+            got = eng.forward_frames(gen, fr, grid)
+            ref = eager.forward_frames(gen, fr, grid)
+            assert torch.equal(_bits(got), _bits(ref)) and len(eng._plans) == 3
+        finally:
+            ops.set_f32_products(old)
 
 
 def test_plan_grows_when_a_count_exceeds_its_capacity(dev, monkeypatch):

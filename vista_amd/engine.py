@@ -379,7 +379,8 @@ class FusedBackbone:
             return self(mean, coords, len(frames), grid)
         if any(f.shape[0] > gen._max_voxels for f in frames) or not 1 <= len(frames) <= 64:
             return self.eager_twin().forward_frames(gen, frames, grid)     # max_voxels truncation: per-frame calls
-        key = (id(gen), len(frames), tuple(grid))
+        # a captured graph holds the kernels chosen when it was recorded: the fp32 matrix arithmetic is part of the key
+        key = (id(gen), len(frames), tuple(grid), int(ops.L.lib().vx_spconv_get_f32_products()))
         plan = self._plans.get(key)
         points = sum(int(f.shape[0]) for f in frames)
         if plan is None or points > plan.cap_points:
