@@ -307,12 +307,15 @@ __device__ __forceinline__ void w8_body(const ConvArgs& a, const long long n_out
   unsigned wmask = 0;
 #pragma unroll
   for (int i = 0; i < kKSlots / 2; ++i) {
+    // unconditional loads from clamped addresses, the select afterwards: a guarded load is waited for inside its
+    // branch, i.e. 14 serial L2 round trips per tile
     const int ks = 2 * i + h;
-    int idx = -1;
-    if (ks < a.kvol && row0 + r < n_out) {
-      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
-      idx = a.nbr[(long long)krow * a.ld + row0 + r];
-    }
+    const bool ok = ks < a.kvol && row0 + r < n_out;
+    const int ksc = ks < a.kvol ? ks : 0;
+    const int krow = a.flip_k ? a.kvol - 1 - ksc : ksc;
+    const long long rr = row0 + r < n_out ? row0 + r : n_out - 1;
+    const int got = a.nbr[(long long)krow * a.ld + rr];
+    const int idx = ok ? got : -1;
     sIdx[ks * 32 + r] = idx;
     const unsigned long long b = __ballot(idx >= 0);
     if ((unsigned)b) wmask |= 1u << (2 * i);
@@ -885,12 +888,15 @@ __global__ __launch_bounds__(kW8Threads, 2) void spconv_w8d(ConvArgs a) {
   unsigned wmask = 0;
 #pragma unroll
   for (int i = 0; i < kKSlots / 2; ++i) {
+    // unconditional loads from clamped addresses, the select afterwards: a guarded load is waited for inside its
+    // branch, i.e. 14 serial L2 round trips per tile
     const int ks = 2 * i + h;
-    int idx = -1;
-    if (ks < a.kvol && row0 + r < n_out) {
-      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
-      idx = a.nbr[(long long)krow * a.ld + row0 + r];
-    }
+    const bool ok = ks < a.kvol && row0 + r < n_out;
+    const int ksc = ks < a.kvol ? ks : 0;
+    const int krow = a.flip_k ? a.kvol - 1 - ksc : ksc;
+    const long long rr = row0 + r < n_out ? row0 + r : n_out - 1;
+    const int got = a.nbr[(long long)krow * a.ld + rr];
+    const int idx = ok ? got : -1;
     sIdx[ks * 32 + r] = idx;
     const unsigned long long b = __ballot(idx >= 0);
     if ((unsigned)b) wmask |= 1u << (2 * i);
@@ -1874,12 +1880,15 @@ __global__ __launch_bounds__(64) void spconv_f32_ws(ConvArgs a, const f32x4* __r
   unsigned wmask = 0;
 #pragma unroll
   for (int i = 0; i < kKSlots / 2; ++i) {
+    // unconditional loads from clamped addresses, the select afterwards: a guarded load is waited for inside its
+    // branch, i.e. 14 serial L2 round trips per tile
     const int ks = 2 * i + h;
-    int idx = -1;
-    if (ks < a.kvol && row0 + r < n_out) {
-      const int krow = a.flip_k ? a.kvol - 1 - ks : ks;
-      idx = a.nbr[(long long)krow * a.ld + row0 + r];
-    }
+    const bool ok = ks < a.kvol && row0 + r < n_out;
+    const int ksc = ks < a.kvol ? ks : 0;
+    const int krow = a.flip_k ? a.kvol - 1 - ksc : ksc;
+    const long long rr = row0 + r < n_out ? row0 + r : n_out - 1;
+    const int got = a.nbr[(long long)krow * a.ld + rr];
+    const int idx = ok ? got : -1;
     sIdx[ks * 32 + r] = idx;
     const unsigned long long b = __ballot(idx >= 0);
     if ((unsigned)b) wmask |= 1u << (2 * i);
