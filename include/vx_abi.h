@@ -256,6 +256,11 @@ int32_t vx_from_dense(const void* d_dense, const int32_t* d_coords, int64_t n, i
  *                             outside batch x in_shape. Workspace vx_rulebook_workspace_bytes(cap_in, batch, out_shape).
  * vx_rulebook_subm_ranked_dn, vx_spconv_fwd_dn, vx_to_dense_dn   as their host-count forms.
  * ------------------------------------------------------------------------------------------- */
+/* Stream-ordered byte fill by a kernel (d_ptr[0..bytes) = value & 0xff): what hipMemsetAsync does, as a KERNEL node.
+ * hipMemsetAsync nodes captured in a HIP graph replay out of order on ROCm 7.2 (DESIGN.md "Sync-free pass"), so a
+ * caller that captures the "_dn" calls clears its count / error words with this. No counterpart in the reference. */
+int32_t vx_fill(void* d_ptr, int32_t value, size_t bytes, void* stream);
+
 int32_t vx_voxelize_hard_batch_dn(const float* d_points, int32_t n_frames, const int64_t* d_frame_offsets,
                                   int64_t cap_points, int32_t n_feat, const float* voxel_size,
                                   const float* range, int32_t max_points, int32_t* d_coords,

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_gpu_parity import random_sites
+from test_gpu_a_parity import random_sites
 
 pytestmark = pytest.mark.gpu
 MODES = [0, 6, 9]
@@ -186,8 +186,8 @@ def test_wgrad_modes_vs_fp64(cin, cout, dev):
 @pytest.mark.parametrize("mode", [0, 9])
 def test_backbone_forward_in_the_other_modes(mode, dev):
     """SpMiddleResNetFHD end to end against the oracle in the two non-default modes (the default runs in
-    test_gpu_parity.test_backbone_forward_vs_oracle and the full-size tests)."""
-    from test_gpu_parity import test_backbone_forward_vs_oracle
+    test_gpu_a_parity.test_backbone_forward_vs_oracle and the full-size tests)."""
+    from test_gpu_a_parity import test_backbone_forward_vs_oracle
     from vista_amd import ops
     ops.set_f32_products(mode)
     test_backbone_forward_vs_oracle("SpMiddleResNetFHD", dev)

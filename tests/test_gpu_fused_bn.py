@@ -118,7 +118,7 @@ def test_fuse_for_training_matches_module_path(dev):
     """SpMiddleResNetFHD with fuse_for_training vs the plain module path (torch BatchNorm1d / ReLU / add) on the
     same frames: same state_dict keys, same loss, same running statistics, same gradients (to the conditioning
     of ~20 stacked train-mode BatchNorm backward passes, see test_backbone_train_step_grads_vs_oracle)."""
-    from test_gpu_parity import _tiny_frames
+    from test_gpu_a_parity import _tiny_frames
     from vista_amd import models
     from vista_amd.fused_bn import FusedBatchNorm1d, fuse_for_training
     from vista_amd.synth import backbone_state_dict
@@ -148,8 +148,8 @@ def test_fuse_for_training_matches_module_path(dev):
         if "num_batches_tracked" in k:
             assert int(sa[k]) == int(sb[k]) == 1
     # conv weight gradients of BOTH paths against the fp64 truth: 1e-4 wherever the ReLU gate pattern agrees with the
-    # fp64 run (see test_gpu_parity._check_grads_against_fp64)
-    from test_gpu_parity import (_check_grads_against_fp64, _check_grads_with_gpu_gates_imposed, _gpu_train_step,
+    # fp64 run (see test_gpu_a_parity._check_grads_against_fp64)
+    from test_gpu_a_parity import (_check_grads_against_fp64, _check_grads_with_gpu_gates_imposed, _gpu_train_step,
                                  _oracle_train_step)
     numel = out_a.numel()
     gates64, gates32 = [], []
@@ -181,7 +181,7 @@ def test_conv_bias_gradient_in_front_of_a_training_norm_is_written_as_zero(dev):
     writes exact zeros for the bias gradient (the reduction over rows it skips yields rounding noise around zero:
     checked here against the unfused path, relative to the size of the terms that cancel) and leaves every other
     gradient bitwise as it was. In eval mode the norm is affine and the bias gradient is reduced as before."""
-    from test_gpu_parity import _tiny_frames
+    from test_gpu_a_parity import _tiny_frames
     from vista_amd import models
     from vista_amd.fused_bn import fuse_for_training
     from vista_amd.synth import backbone_state_dict

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def test_training_step_through_rccl_world1_equals_single_process_step():
     import torch.distributed as dist
-    from test_gpu_parity import _tiny_frames
+    from test_gpu_a_parity import _tiny_frames
     from vista_amd import models
     from vista_amd.fused_bn import fuse_for_training
     from vista_amd.synth import backbone_state_dict

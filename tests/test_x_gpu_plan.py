@@ -194,3 +194,79 @@ def test_plan_grows_when_a_count_exceeds_its_capacity(dev, monkeypatch):
     ref = eng.eager_twin().forward_frames(gen, fr, grid)
     assert torch.equal(_bits(got), _bits(ref))
     assert len(builds) == 2              # one overflow, one re-plan from an exact geometry pass
+
+
+# ---- full-size cases through the plan, and plan lifetime (round 3) ---------------------------------------------------
+@pytest.mark.parametrize("dispatch", ["queued", "graph"])
+def test_vista_frame_multiview_backbone_vs_oracle_planned(dispatch, dev):
+    """BASELINE configs[2], sparse part, full size, through the sync-free plan (queued and captured)."""
+    from _fullsize_cases import vista_multiview_case
+    vista_multiview_case(dev, dispatch=dispatch)
+
+
+@pytest.mark.parametrize("dispatch", ["queued", "graph"])
+def test_stress_frame_end_to_end_vs_oracle_planned(dispatch, dev):
+    """BASELINE configs[3], full size, fp32 then bf16 engines one after the other (two STRESS-sized captures in a row:
+    the case that aborted in round 2's driver run, DESIGN.md "Plan lifetime")."""
+    from _fullsize_cases import stress_case
+    stress_case(dev, dispatch=dispatch)
+
+
+def test_plans_of_two_engines_built_abandoned_and_rebuilt(dev):
+    """Captured plans of two engines in one process: build, abandon (with and without a reference cycle that only the
+    cyclic collector can break), rebuild, and capture again while garbage holding a graph is pending. Results stay
+    bitwise those of the eager path throughout and every abandoned plan ends up closed."""
+    import gc
+    import weakref
+    from vista_amd.synth import GEOMETRIES, grid_size
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES["SMALL"]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    fr = _frames(dev, [21, 22], 3)
+    ref32 = _engine("SpMiddleResNetFHD", dev, torch.float32, "graph").eager_twin().forward_frames(gen, fr, grid)
+    ref16 = _engine("SpMiddleResNetFHD", dev, torch.bfloat16, "graph").eager_twin().forward_frames(gen, fr, grid)
+    plans = []
+    for round_ in range(3):
+        a = _engine("SpMiddleResNetFHD", dev, torch.float32, "graph")
+        out = a.forward_frames(gen, fr, grid)
+        assert torch.equal(_bits(out), _bits(ref32))
+        plans += [weakref.ref(p) for p in a._plans.values()]
+        if round_ == 1:
+            a.self_reference = a           # a cycle: only the collector can free this engine
+        del a, out                         # abandoned; round 1's stays pending as garbage with its graph alive
+        b = _engine("SpMiddleResNetFHD", dev, torch.bfloat16, "graph")
+        out = b.forward_frames(gen, fr, grid)          # captures while the garbage above may still be pending
+        assert torch.equal(_bits(out), _bits(ref16))
+        # the same engine re-plans (larger batch -> new key; then an explicit close and a rebuild of the first key)
+        out3 = b.forward_frames(gen, fr + _frames(dev, [23], 3), grid)
+        assert out3.shape[0] == 3
+        b.close()
+        assert not b._plans
+        out = b.forward_frames(gen, fr, grid)
+        assert torch.equal(_bits(out), _bits(ref16))
+        plans += [weakref.ref(p) for p in b._plans.values()]
+        del b, out, out3
+    gc.collect()
+    assert all(p() is None or p().closed for p in plans)
+
+
+def test_plan_error_word_is_not_sticky(dev):
+    """A frame set with an out-of-grid coordinate raises; the next valid call on the SAME plan works."""
+    from vista_amd._lib import VxError
+    from vista_amd.synth import GEOMETRIES, grid_size
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES["SMALL"]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    eng = _engine("SpMiddleResNetFHD", dev, torch.float32, "graph")
+    fr = _frames(dev, [31], 3)
+    ref = eng.eager_twin().forward_frames(gen, fr, grid)
+    assert torch.equal(_bits(eng.forward_frames(gen, fr, grid)), _bits(ref))
+    plan = next(iter(eng._plans.values()))
+    plan.counts[0:1].fill_(1)              # what vx_rulebook_conv_dn leaves behind after a bad coordinate
+    plan.h_counts[0] = 1
+    with pytest.raises(VxError, match="outside batch"):
+        plan.overflow()
+    assert torch.equal(_bits(eng.forward_frames(gen, fr, grid)), _bits(ref))     # cleared inside the step
+    assert next(iter(eng._plans.values())) is plan

@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
-from test_gpu_parity import _gpu_train_step, _oracle_train_step, _tiny_frames
+from test_gpu_a_parity import _gpu_train_step, _oracle_train_step, _tiny_frames
 from vista_amd.synth import backbone_state_dict
 dev = torch.device("cuda:0")
 clouds, mean, coords, grid, _ = _tiny_frames(dev, 2)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "vx_spconv_get_f32_products": (c_int32, []),
     "vx_to_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,
                               c_int32, c_void_p]),
+    "vx_fill": (c_int32, [c_void_p, c_int32, c_size_t, c_void_p]),
     "vx_voxelize_hard_batch_dn": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_f32p, c_f32p, c_int32,
                                             c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
                                             c_void_p]),
@@ -98,6 +99,35 @@ SIGNATURES = {
 
 _lib = None
 
+# VX_TRACE=1: one line on stderr BEFORE every C-ABI call (entry point, "[capturing]" when the current stream is being
+# captured), flushed at once, so that a fatal failure below Python (a HIP runtime abort, a GPU fault) names the call
+# it happened in. Off by default: nothing is wrapped and calls go straight to the ctypes functions.
+TRACE = os.environ.get("VX_TRACE", "0") not in ("", "0")
+
+
+def trace(msg):
+    if TRACE:
+        import sys
+        sys.stderr.write(f"[vx] {msg}\n")
+        sys.stderr.flush()
+
+
+class _Traced:
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name in ("vx_last_error", "vx_version") or name.endswith("_bytes") or "f32_products" in name:
+            return fn
+
+        def call(*args):
+            import torch
+            cap = " [capturing]" if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing() else ""
+            trace(f"{name}{cap}")
+            return fn(*args)
+        return call
+
 
 class VxError(RuntimeError):
     pass
@@ -116,7 +146,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
-        _lib = L
+        _lib = _Traced(L) if TRACE else L
     return _lib
 
 

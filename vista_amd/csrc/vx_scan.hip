@@ -138,6 +138,12 @@ int32_t vx_fill_async(void* d_ptr, int value, size_t bytes, hipStream_t stream) 
   return VX_OK;
 }
 
+// public form (include/vx_abi.h): the capturable clear a caller of the "_dn" entry points needs for its count vector
+extern "C" int32_t vx_fill(void* d_ptr, int32_t value, size_t bytes, void* stream) {
+  VX_REQUIRE(d_ptr != nullptr || bytes == 0, "vx_fill: null pointer");
+  return vx_fill_async(d_ptr, value, bytes, (hipStream_t)stream);
+}
+
 size_t vx_scan_workspace_bytes(int64_t n) {
   size_t bytes = 0;
   int64_t m = vx_cdiv(n > 0 ? n : 1, kTile);

@@ -3,6 +3,8 @@ with BatchNorm1d(eval) + bias + ReLU + residual folded into the conv kernel's ep
 (scn.py:82-98 collapses from 2 GEMM sets + 4 elementwise passes to 2 launches per block) and all
 rulebooks of a frame built before the feature pass (they depend on coordinates only).
 """
+import contextlib
+import gc
 import os
 
 import numpy as np
@@ -157,6 +159,46 @@ def _run_dn(steps, st, caps, counts, slot, err, geom_only=False, mark=None):
     return st
 
 
+class _Compiled:
+    """The fused step lists of one backbone. Shared by an engine, its eager twin and its plans, and holding no
+    reference back to any of them: a plan never keeps its engine alive (round 2's FramePlan.engine <-> FusedBackbone._plans
+    cycle left abandoned graphs to the cyclic collector, see _capture_guard)."""
+    __slots__ = ("kind", "mode", "middle", "bev", "rv")
+
+    def __init__(self, kind, mode, middle, bev=None, rv=None):
+        self.kind, self.mode, self.middle, self.bev, self.rv = kind, mode, middle, bev, rv
+
+
+# Stream capture and object teardown do not mix. On ROCm ~CUDAGraph() calls hipDeviceSynchronize() (and releases the
+# graph's private pool); under an active capture that call is refused, the C++ destructor throws, and the process
+# dies with SIGABRT. torch >= 2.9 no longer runs gc.collect() when a capture begins (torch.compiler.config
+# .force_cudagraph_gc is off), so a graph that is only reachable through a reference cycle is destroyed whenever
+# the cyclic collector happens to run -- in round 2 that was in the middle of the next engine's capture
+# (GPUTEST_r02: abort inside FramePlan.capture of the second STRESS engine). Hence: plans are closed explicitly and
+# deterministically (FramePlan.close), the collector runs BEFORE a capture begins and is switched off for its duration,
+# and a close() requested while a capture is open is deferred until it has ended.
+_capture_depth = 0
+_deferred_close = []
+
+
+@contextlib.contextmanager
+def _capture_guard():
+    global _capture_depth
+    gc.collect()                       # anything holding a graph or a pool goes now, outside the capture
+    was_enabled = gc.isenabled()
+    gc.disable()
+    _capture_depth += 1
+    try:
+        yield
+    finally:
+        _capture_depth -= 1
+        if was_enabled:
+            gc.enable()
+        if _capture_depth == 0:
+            while _deferred_close:
+                _deferred_close.pop().close()
+
+
 class FramePlan:
     """Voxelization + backbone for `n_frames` clouds without one host synchronisation inside the step.
 
@@ -167,12 +209,12 @@ class FramePlan:
       "graph" : recorded once in a HIP graph and replayed with a single graph launch (no Python dispatch at all).
     After the step the counts come back in one small copy; a count above its capacity means rows were dropped, and
     the caller (FusedBackbone.forward_frames) re-plans with larger capacities. Results are bitwise those of the eager
-    path (tests/test_gpu_plan.py)."""
+    path (tests/test_x_gpu_plan.py)."""
 
     COUNT_SLOTS = 16     # strided convs a plan may hold
 
-    def __init__(self, engine, gen, n_frames, grid, cap_points, cap_rows, caps, dev):
-        self.engine, self.gen, self.n_frames, self.grid = engine, gen, int(n_frames), list(grid)
+    def __init__(self, compiled, gen, n_frames, grid, cap_points, cap_rows, caps, dev):
+        self.engine, self.gen, self.n_frames, self.grid = compiled, gen, int(n_frames), list(grid)   # engine: a _Compiled
         self.cap_points, self.cap_rows, self.caps = int(cap_points), int(cap_rows), [int(c) for c in caps]
         if len(self.caps) > self.COUNT_SLOTS:
             raise ValueError("too many strided convolutions for one plan")
@@ -186,11 +228,13 @@ class FramePlan:
         self.h_offsets = torch.zeros((nf + 1,), dtype=torch.int64).pin_memory()
         self.graph = None
         self.out = None
+        self.closed = False
         self.limit = None          # diagnostic (tools/graph_probe.py): stop after this many steps of the middle stack
         # Rulebooks depend on coordinates only: they are built on a second stream (a parallel branch of the captured
         # graph) while the first stage's convolutions run, each handed over through an event. Same kernels on the same
         # inputs: outputs are unchanged. VX_GEOM_OVERLAP=0 keeps everything on one stream.
         self.geom_stream = torch.cuda.Stream(dev) if os.environ.get("VX_GEOM_OVERLAP", "1") != "0" else None
+        self._events, self._next_event = [], 0
 
     def _geometry_ahead(self, st, args):
         """All rulebooks of the plan on the geometry stream, in the order the feature pass meets them."""
@@ -200,8 +244,13 @@ class FramePlan:
         side.wait_stream(main)                     # after the voxelizer
 
         def mark(rb):
-            rb.ready = torch.cuda.Event()
+            # events come from the plan's own pool (created before any capture, re-used by every pass)
+            if self._next_event == len(self._events):
+                self._events.append(torch.cuda.Event())
+            rb.ready = self._events[self._next_event]
+            self._next_event += 1
             rb.ready.record(side)
+        self._next_event = 0
         with torch.cuda.stream(side):
             mid = _run_dn(e.middle, st, *args, geom_only=True, mark=mark)
             if e.kind != "SpMiddleResNetFHD":
@@ -211,6 +260,9 @@ class FramePlan:
     def _forward(self):
         from . import ops_dn
         e, g = self.engine, self.gen
+        # the out-of-grid error word is part of the step: cleared here (a kernel node), so one bad frame does not
+        # poison every later call on this plan
+        ops.fill_(self.counts[0:1], 0)
         mean, coords, _ = ops_dn.voxelize_batch_dn(self.points, self.offsets, self.n_frames, g.voxel_size,
                                                    g.point_cloud_range, g.max_num_points_per_voxel, self.cap_rows,
                                                    self.counts[1:2 + self.n_frames])
@@ -255,10 +307,37 @@ class FramePlan:
             self._forward()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
-            self.out = self._forward()
+        del side
+        graph = torch.cuda.CUDAGraph()
+        with _capture_guard():
+            ops.L.trace("capture begin")
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"), torch.no_grad():
+                self.out = self._forward()
+            ops.L.trace("capture end")
+        self.graph = graph
         return self
+
+    def close(self):
+        """Destroy the captured graph and give the plan's buffers back -- NOW, never at collector time, and never
+        inside a capture (then it is deferred to the capture's end). Idempotent; the plan cannot run afterwards."""
+        if _capture_depth > 0:
+            if self not in _deferred_close:
+                _deferred_close.append(self)
+            return
+        graph, self.graph, self.out = self.graph, None, None
+        if graph is not None:
+            torch.cuda.synchronize(self.dev)       # no replay of it in flight
+            graph.reset()                          # hipGraphExecDestroy + release of its private pool
+            del graph
+        self.points = self.offsets = self.counts = None
+        self.closed = True
+
+    def __del__(self):
+        try:
+            if not getattr(self, "closed", True):
+                self.close()
+        except Exception:
+            pass
 
     def stage(self, frames):
         """Copy the clouds into the plan's input buffer and upload their point ranges (stream-ordered, no sync)."""
@@ -272,6 +351,8 @@ class FramePlan:
         self.offsets.copy_(self.h_offsets, non_blocking=True)
 
     def replay(self):
+        if self.closed:
+            raise ops.L.VxError("FramePlan: replay() after close()")
         if self.graph is not None:
             self.graph.replay()
         else:                       # "queued": the same launch sequence straight onto the current stream
@@ -311,13 +392,28 @@ class FusedBackbone:
             raise ValueError("dispatch must be 'queued' or 'graph'")
         self.mode = getattr(module, "mode", "bev")
         self.middle = _compile_sequential(module.middle_conv, dev, dtype)
+        self.bev = self.rv = None
         if self.kind == "MultiViewBackbone":
             self.bev = _compile_sequential(module.bev_conv, dev, dtype)
             self.rv = _compile_sequential(module.rv_conv, dev, dtype)
         elif self.kind != "SpMiddleResNetFHD":
             raise TypeError(f"unsupported backbone {self.kind}")
+        self._compiled = _Compiled(self.kind, self.mode, self.middle, self.bev, self.rv)
         self._plans = {}
         self._twin = None
+
+    def close(self):
+        """Destroy every captured plan of this engine (graphs, private pools, buffers). Called when the engine is
+        dropped; call it yourself to release the memory earlier."""
+        plans, self._plans = list(getattr(self, "_plans", {}).values()), {}
+        for p in plans:
+            p.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def dispatch_name(self):
         if self.eager:
@@ -366,7 +462,9 @@ class FusedBackbone:
         if old is not None:
             cap_points, cap_rows = max(cap_points, old.cap_points), max(cap_rows, old.cap_rows)
             caps = [max(a, b) for a, b in zip(caps, old.caps)]
-        plan = FramePlan(self, gen, len(frames), grid, cap_points, cap_rows, caps, frames[0].device)
+        if old is not None:
+            old.close()                # its graph and pool go before the new plan allocates and captures
+        plan = FramePlan(self._compiled, gen, len(frames), grid, cap_points, cap_rows, caps, frames[0].device)
         plan.stage(frames)
         return plan.capture() if self.dispatch == "graph" else plan
 

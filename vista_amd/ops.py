@@ -28,6 +28,16 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+def fill_(t, value=0):
+    """Stream-ordered byte fill of a contiguous CUDA tensor by a kernel (vx_fill): the capturable clear."""
+    _need_gpu(t, "tensor")
+    if not t.is_contiguous():
+        raise ValueError("fill_: tensor must be contiguous")
+    with torch.cuda.device(t.device):
+        L.check(L.lib().vx_fill(_ptr(t), int(value), t.numel() * t.element_size(), _stream()), "vx_fill")
+    return t
+
+
 _DT = {torch.float32: L.VX_F32, torch.bfloat16: L.VX_BF16}
 
 # bench.py sets this to a list to get HIP-event pairs (recorded on the launch stream) around every
