@@ -10,7 +10,11 @@
  *  - every launch goes to the caller's stream (void* = hipStream_t, e.g.
  *    torch.cuda.current_stream().cuda_stream) and is asynchronous, except where a function is
  *    documented to return a host count (one small D2H copy + stream synchronize);
- *  - re-entrant and thread-safe (no mutable globals besides the thread-local error text).
+ *  - re-entrant and thread-safe. Process-wide state, all of it listed here: the thread-local error text; the DEFAULT
+ *    fp32 matrix arithmetic (vx_spconv_set_f32_products: an atomic int that only calls WITHOUT a VX_CONV_F32_* flag
+ *    read -- pass the flag and two threads / captured plans with different arithmetics cannot interfere); the
+ *    per-device scratch array of vx_voxelize_hard_static (documented there: one call at a time per GPU);
+ *    read-only per-device caches (CU count, address of a zero row).
  *
  * What each entry point replaces in the reference is cited as file:line under /root/reference.
  * The reference's FFI for the sparse part is the third-party `spconv` package (not vendored:
@@ -44,6 +48,12 @@ extern "C" {
    16-pair compaction kernel (fp32 cin = 64) runs its last partial round as a second launch on half-height tiles
    (same sums, bitwise identical output); this flag launches the plain grids instead (A/B timing, tests) */
 #define VX_CONV_NO_SPLIT_TAIL 0x200
+/* matrix arithmetic of THIS call for fp32 operands (vx_spconv_fwd / _dn / dgrad / wgrad `flags`; see
+   vx_spconv_set_f32_products below for what the three mean). 0 in these bits = the process default. */
+#define VX_CONV_ARITH_MASK 0x3000
+#define VX_CONV_F32_MFMA 0x1000       /* v_mfma_f32_32x32x2_f32 */
+#define VX_CONV_F32_PRODUCTS6 0x2000  /* six of the nine exact bf16 plane products */
+#define VX_CONV_F32_PRODUCTS9 0x3000  /* all nine */
 
 int32_t vx_version(void);
 const char* vx_last_error(void);
@@ -191,29 +201,31 @@ int32_t vx_spconv_pack_weight(const void* d_weight, int32_t cin, int32_t cout, i
  * (weight.permute(4,1,2,3,0)). For a submanifold conv pass the forward table with subm=1
  * (nbr_t[k] == nbr[kvol-1-k]); for a strided conv pass the transpose table of
  * vx_rulebook_conv_emit. Replaces spconv's input gradient reached through autograd at
- * det3d/core/utils/dist_utils.py:50-56 (loss.backward()). */
+ * det3d/core/utils/dist_utils.py:50-56 (loss.backward()). flags: VX_CONV_F32_* or 0. */
 int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t cout, const void* d_weight_t,
                         int32_t kvol, int32_t cin, const int32_t* d_nbr_t, int64_t nbr_t_ld,
-                        int64_t n_in, int32_t subm, void* d_din, int32_t dtype, void* stream);
+                        int64_t n_in, int32_t subm, int32_t flags, void* d_din, int32_t dtype, void* stream);
 
 /* wgrad: dW[co][k][ci] = sum over the pairs (i,o) of offset k of dout[o][co] * in[i][ci], from the
  * compacted pair lists of vx_nbr_to_pairs (exact FLOPs); two-pass slab reduction, atomic-free and
- * bitwise reproducible. d_dw f32[cout][kvol][cin]. Replaces spconv's weight gradient reached
- * through autograd at det3d/core/utils/dist_utils.py:50-56 (loss.backward()). */
+ * bitwise reproducible. d_dw f32[cout][kvol][cin] is OVERWRITTEN (it may be any device address, e.g. the
+ * parameter's slice of a flat gradient buffer). flags: VX_CONV_F32_* or 0. Replaces spconv's weight gradient
+ * reached through autograd at det3d/core/utils/dist_utils.py:50-56 (loss.backward()). */
 size_t vx_spconv_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t kvol, int64_t n_out);
 int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, const void* d_dout,
                         int64_t n_out, int32_t cout, const int32_t* d_pairs,
-                        const int32_t* d_pair_num, int32_t kvol, float* d_dw, int32_t dtype,
+                        const int32_t* d_pair_num, int32_t kvol, float* d_dw, int32_t dtype, int32_t flags,
                         void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* Process-wide choice of the matrix arithmetic of the fp32 convolutions with Cin >= 64 (forward and dgrad):
+/* DEFAULT matrix arithmetic of the fp32 convolutions with Cin >= 64 (forward, dgrad) and of the weight gradients
+ * with Cin, Cout multiples of 32, used by calls whose flags carry no VX_CONV_F32_* bits:
  *   0  v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense on MI355X)
  *   9  every fp32 operand split exactly into three bf16 planes (x = h + m + l), all nine plane products on
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation: each fp32 x fp32 product enters the sum exactly; 9/16 of
  *      the fp32 MFMA's cycles
  *   6  the same without the three smallest plane products (each below 2^-23 of |a*b|); 6/16 of the cycles
- * Inputs, weights, outputs and the accumulators stay fp32 in all three. Default: VX_F32_PRODUCTS in the
- * environment at load time, else 0. No counterpart in the reference (spconv picks its own GEMM kernels); the
+ * Inputs, weights, outputs and the accumulators stay fp32 in all three. Initial value: VX_F32_PRODUCTS in the
+ * environment at load time, else 6. No counterpart in the reference (spconv picks its own GEMM kernels); the
  * tolerance of the path (1e-4 relative in fp32, BASELINE.json north_star) is tested in all three modes. */
 int32_t vx_spconv_set_f32_products(int32_t products);
 int32_t vx_spconv_get_f32_products(void);

@@ -191,3 +191,69 @@ def test_backbone_forward_in_the_other_modes(mode, dev):
     from vista_amd import ops
     ops.set_f32_products(mode)
     test_backbone_forward_vs_oracle("SpMiddleResNetFHD", dev)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (32, 32)])
+def test_per_call_arithmetic_flag_overrides_the_process_default(cin, cout, dev):
+    """VX_CONV_F32_* in a call's flags (vx_spconv_fwd / _dn / dgrad / wgrad) selects that call's arithmetic whatever the
+    process default is: bitwise the result of the same call under the matching default."""
+    from vista_amd import ops, ops_dn
+    rng = np.random.default_rng(cin + 7 * cout)
+    shape = [9, 40, 40]
+    coords = torch.from_numpy(random_sites(rng, 2, shape, 2600)).to(dev)
+    n = coords.shape[0]
+    feat = torch.from_numpy(_wide(rng, (n, cin))).to(dev)
+    w = torch.from_numpy(_wide(rng, (cout, 3, 3, 3, cin)) / np.float32(np.sqrt(27 * cin))).to(dev)
+    gout = torch.from_numpy(_wide(rng, (n, cout))).to(dev)
+    rb = ops.rulebook_subm(coords, 2, shape, 3)
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    rbd = ops_dn.rulebook_subm_dn(coords, cnt, 2, shape, 3)
+    want = {}
+    for mode in MODES:
+        ops.set_f32_products(mode)
+        want[mode] = (ops.conv_fwd(feat, w, rb), ops.conv_dgrad(gout, w, rb), ops.conv_wgrad(feat, gout, rb, w.shape))
+    for default in MODES:
+        ops.set_f32_products(default)
+        for mode in MODES:
+            got = (ops.conv_fwd(feat, w, rb, products=mode), ops.conv_dgrad(gout, w, rb, products=mode),
+                   ops.conv_wgrad(feat, gout, rb, w.shape, products=mode))
+            for g, r in zip(got, want[mode]):
+                assert torch.equal(g, r), (default, mode)
+            assert torch.equal(ops_dn.conv_fwd_dn(feat, w, rbd, products=mode), want[mode][0])
+    if cin >= 64:      # the three arithmetics do differ at these widths (otherwise the test above proves nothing)
+        assert not torch.equal(want[0][0], want[6][0])
+    with pytest.raises(ValueError):
+        ops.conv_fwd(feat, w, rb, products=7)
+    # wgrad into a caller-provided destination (a slice of a flat gradient buffer): same bits, destination overwritten
+    flat = torch.full((w.numel() + 64,), float("nan"), device=dev)
+    dst = flat[32:32 + w.numel()].view_as(w)
+    out = ops.conv_wgrad(feat, gout, rb, w.shape, products=6, out=dst)
+    assert out.data_ptr() == dst.data_ptr() and torch.equal(dst, want[6][2])
+    assert bool(torch.isnan(flat[:32]).all()) and bool(torch.isnan(flat[32 + w.numel():]).all())
+
+
+def test_engine_arithmetic_is_an_engine_property(dev):
+    """Two engines with different f32_products in one process, interleaved: each keeps its own arithmetic (captured
+    plans included) while the process default is changed under them."""
+    from vista_amd import models, ops
+    from vista_amd.engine import FusedBackbone
+    from vista_amd.synth import GEOMETRIES, backbone_state_dict, grid_size, lidar_cloud
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES["SMALL"]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    net = models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5),
+                                       backbone_state_dict("SpMiddleResNetFHD")).to(dev).eval()
+    fr = [torch.from_numpy(lidar_cloud(seed=41, sweeps=3)).to(dev)]
+    ref = {}
+    for mode in (0, 6):
+        ops.set_f32_products(mode)
+        ref[mode] = FusedBackbone(net, eager=True).forward_frames(gen, fr, grid).clone()
+    assert not torch.equal(ref[0], ref[6])
+    e0 = FusedBackbone(net, dispatch="graph", f32_products=0)
+    e6 = FusedBackbone(net, dispatch="graph", f32_products=6)
+    for default in (6, 0, 9, 6):
+        ops.set_f32_products(default)
+        assert torch.equal(e0.forward_frames(gen, fr, grid), ref[0])
+        assert torch.equal(e6.forward_frames(gen, fr, grid), ref[6])
+    assert len(e0._plans) == 1 and len(e6._plans) == 1

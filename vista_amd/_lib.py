@@ -17,6 +17,8 @@ VX_F32, VX_BF16 = 0, 1
 VX_EPI_RELU = 1
 VX_CONV_NO_COMPACT = 0x100
 VX_CONV_NO_SPLIT_TAIL = 0x200
+VX_CONV_F32_MFMA, VX_CONV_F32_PRODUCTS6, VX_CONV_F32_PRODUCTS9 = 0x1000, 0x2000, 0x3000
+ARITH_FLAG = {None: 0, 0: VX_CONV_F32_MFMA, 6: VX_CONV_F32_PRODUCTS6, 9: VX_CONV_F32_PRODUCTS9}
 
 # name -> (restype, argtypes); mirrors include/vx_abi.h one to one
 SIGNATURES = {
@@ -56,10 +58,10 @@ SIGNATURES = {
     "vx_rulebook_sort_rows": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int64, c_void_p,
                                         c_void_p]),
     "vx_spconv_dgrad": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p,
-                                  c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
+                                  c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "vx_spconv_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),
     "vx_spconv_wgrad": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
-                                  c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+                                  c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "vx_spconv_set_f32_products": (c_int32, [c_int32]),
     "vx_spconv_get_f32_products": (c_int32, []),
     "vx_to_dense": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_i32p, c_void_p,

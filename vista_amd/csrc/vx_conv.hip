@@ -2097,6 +2097,16 @@ extern "C" int32_t vx_spconv_set_f32_products(int32_t products) {
 
 extern "C" int32_t vx_spconv_get_f32_products(void) { return f32_products_mode().load(std::memory_order_relaxed); }
 
+// arithmetic of one call: its VX_CONV_F32_* flag, else the process default
+int vx_resolve_f32_products(int32_t flags) {
+  switch (flags & VX_CONV_ARITH_MASK) {
+    case VX_CONV_F32_MFMA: return 0;
+    case VX_CONV_F32_PRODUCTS6: return 6;
+    case VX_CONV_F32_PRODUCTS9: return 9;
+    default: return f32_products_mode().load(std::memory_order_relaxed);
+  }
+}
+
 static int32_t spconv_fwd_impl(const void* d_in, int64_t n_in, int32_t cin, const void* d_weight,
                                int32_t kvol, int32_t cout, const int32_t* d_nbr, int64_t nbr_ld,
                                int64_t n_out, const int64_t* d_n_out, const float* d_bias,
@@ -2134,7 +2144,7 @@ static int32_t spconv_fwd_impl(const void* d_in, int64_t n_in, int32_t cin, cons
   a.perm = d_perm;
   a.n_out_dev = (const long long*)d_n_out;
   a.cus = cu_count();
-  a.f32_products = f32_products_mode().load(std::memory_order_relaxed);
+  a.f32_products = vx_resolve_f32_products(flags);
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
   if (!(flags & VX_CONV_NO_COMPACT)) {   // fp32, Cin in {16,32,64}, Cout <= 128: per-offset compaction kernel
     const int32_t rc = dispatch_cb(a, (hipStream_t)stream);
@@ -2188,7 +2198,7 @@ extern "C" int32_t vx_spconv_pack_weight(const void* d_weight, int32_t cin, int3
 extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t cout,
                                    const void* d_weight, int32_t kvol, int32_t cin,
                                    const int32_t* d_nbr_t, int64_t nbr_t_ld, int64_t n_in,
-                                   int32_t subm, void* d_din, int32_t dtype, void* stream) {
+                                   int32_t subm, int32_t flags, void* d_din, int32_t dtype, void* stream) {
   VX_REQUIRE(dtype == VX_F32 || dtype == VX_BF16, "spconv_dgrad: dtype must be VX_F32 or VX_BF16");
   VX_REQUIRE(cout >= 1 && cout <= 128 && cin >= 1 && kvol >= 1 && kvol <= 125,
              "spconv_dgrad: need 1 <= cout <= 128, cin >= 1, 1 <= kvol <= 125");
@@ -2216,7 +2226,7 @@ extern "C" int32_t vx_spconv_dgrad(const void* d_dout, int64_t n_out, int32_t co
   a.perm = nullptr;
   a.n_out_dev = nullptr;
   a.cus = cu_count();
-  a.f32_products = f32_products_mode().load(std::memory_order_relaxed);
+  a.f32_products = vx_resolve_f32_products(flags);
   if (int32_t rc = zero_row_address(&a.zero)) return rc;
   {
     const int32_t rc = dispatch_cb(a, (hipStream_t)stream);

@@ -400,7 +400,7 @@ void launch_partial(const float* in, int cin, const float* dout, int cout, const
 }
 }  // namespace
 
-extern "C" int32_t vx_spconv_get_f32_products(void);   // vx_conv.hip: the process-wide fp32 matrix arithmetic
+int vx_resolve_f32_products(int32_t flags);   // vx_conv.hip: the call's VX_CONV_F32_* flag, else the process default
 
 extern "C" size_t vx_spconv_wgrad_workspace_bytes(int32_t cin, int32_t cout, int32_t kvol,
                                                   int64_t n_out) {
@@ -416,15 +416,14 @@ extern "C" size_t vx_spconv_wgrad_workspace_bytes(int32_t cin, int32_t cout, int
 extern "C" int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, const void* d_dout,
                                    int64_t n_out, int32_t cout, const int32_t* d_pairs,
                                    const int32_t* d_pair_num, int32_t kvol, float* d_dw,
-                                   int32_t dtype, void* d_ws, size_t ws_bytes, void* stream_) {
+                                   int32_t dtype, int32_t flags, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   VX_REQUIRE(dtype == VX_F32, "spconv_wgrad: only VX_F32 is built in this revision");
   VX_REQUIRE(cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128 && kvol >= 1 && kvol <= 125,
              "spconv_wgrad: need 1 <= cin, cout <= 128, 1 <= kvol <= 125");
   VX_REQUIRE(d_dw && n_in >= 0 && n_out >= 0, "spconv_wgrad: bad arguments");
   if (n_out == 0 || n_in == 0) {
-    VX_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * kvol * cin, stream));
-    return VX_OK;
+    return vx_fill_async(d_dw, 0, sizeof(float) * (size_t)cout * kvol * cin, stream);
   }
   VX_REQUIRE(d_in && d_dout && d_pairs && d_pair_num && d_ws, "spconv_wgrad: null pointer");
   if (ws_bytes < vx_spconv_wgrad_workspace_bytes(cin, cout, kvol, n_out)) {
@@ -435,7 +434,7 @@ extern "C" int32_t vx_spconv_wgrad(const void* d_in, int64_t n_in, int32_t cin, 
   if (tm == 3) tm = 4;
   if (tn == 3) tn = 4;
   VX_REQUIRE(n_out < (1ll << 31) && n_in < (1ll << 31), "spconv_wgrad: row ids must fit int32");
-  const int products = vx_spconv_get_f32_products();
+  const int products = vx_resolve_f32_products(flags);
   const int nchunks = (int)vx_cdiv(n_out, kChunkRows);
   const float* in = (const float*)d_in;
   const float* dout = (const float*)d_dout;

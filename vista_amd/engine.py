@@ -79,7 +79,7 @@ class _State:
         self.rank = rank  # rank table of idx when idx came out of a strided conv
 
 
-def _run(steps, st, geom_only=False):
+def _run(steps, st, geom_only=False, products=None):
     st = _State(st.feat, st.idx, st.shape, st.batch, st.cache, st.rank)
     identity = None
     for s in steps:
@@ -102,7 +102,7 @@ def _run(steps, st, geom_only=False):
                 # first layer: the voxelizer's fp32 means (Cin=5) run through the fp32 kernel
                 w = s.w32
             st.feat = ops.conv_fwd(st.feat, w, rb, bias=s.bias, scale=s.scale, shift=s.shift,
-                                   residual=res, relu=s.relu, wpack=s.wpack if w is s.w else None)
+                                   residual=res, relu=s.relu, wpack=s.wpack if w is s.w else None, products=products)
             if st.feat.dtype != s.w.dtype:
                 st.feat = st.feat.to(s.w.dtype)
         if s.kind == "conv":
@@ -110,7 +110,7 @@ def _run(steps, st, geom_only=False):
     return st
 
 
-def _run_dn(steps, st, caps, counts, slot, err, geom_only=False, mark=None):
+def _run_dn(steps, st, caps, counts, slot, err, geom_only=False, mark=None, products=None):
     """_run with device-resident row counts (vista_amd.ops_dn): no host sync anywhere. `caps[j]` / `counts[slot + j]`
     = output capacity / count slot of the j-th strided conv met (in call order over the whole plan).
     geom_only: build the rulebooks only (they depend on coordinates alone); `mark(rb)` is called on every rulebook
@@ -151,7 +151,7 @@ def _run_dn(steps, st, caps, counts, slot, err, geom_only=False, mark=None):
             if st.feat.dtype != w.dtype:
                 w = s.w32
             st.feat = ops_dn.conv_fwd_dn(st.feat, w, rb, bias=s.bias, scale=s.scale, shift=s.shift, residual=res,
-                                         relu=s.relu)
+                                         relu=s.relu, products=products)
             if st.feat.dtype != s.w.dtype:
                 st.feat = st.feat.to(s.w.dtype)
         if s.kind == "conv":
@@ -213,7 +213,8 @@ class FramePlan:
 
     COUNT_SLOTS = 16     # strided convs a plan may hold
 
-    def __init__(self, compiled, gen, n_frames, grid, cap_points, cap_rows, caps, dev):
+    def __init__(self, compiled, gen, n_frames, grid, cap_points, cap_rows, caps, dev, products=None):
+        self.products = products     # fp32 matrix arithmetic of every conv call of this plan (flags of vx_spconv_fwd_dn)
         self.engine, self.gen, self.n_frames, self.grid = compiled, gen, int(n_frames), list(grid)   # engine: a _Compiled
         self.cap_points, self.cap_rows, self.caps = int(cap_points), int(cap_rows), [int(c) for c in caps]
         if len(self.caps) > self.COUNT_SLOTS:
@@ -272,7 +273,7 @@ class FramePlan:
         args = (self.caps, self.counts, self.slot, self.counts[0:1])
         from . import ops_dn as od
         if self.limit is not None:
-            mid = _run_dn(e.middle[:self.limit], st, *args)
+            mid = _run_dn(e.middle[:self.limit], st, *args, products=self.products)
             return mid.feat, mid.idx
         if self.geom_stream is not None:
             self._geometry_ahead(st, args)
@@ -284,16 +285,17 @@ class FramePlan:
 
     def _features(self, st, args, od):
         e = self.engine
-        mid = _run_dn(e.middle, st, *args)
+        pr = dict(products=self.products)
+        mid = _run_dn(e.middle, st, *args, **pr)
         if e.kind == "SpMiddleResNetFHD":
             d = od.to_dense_dn(mid.feat, mid.idx, mid.n, mid.batch, mid.shape)
             n, c, dd, h, w = d.shape
             return d.view(n, c * dd, h, w) if e.mode == "bev" else d
-        b = _run_dn(e.bev, mid, *args)
+        b = _run_dn(e.bev, mid, *args, **pr)
         bev = od.to_dense_dn(b.feat, b.idx, b.n, b.batch, b.shape)
         n, c, d, h, w = bev.shape
         bev = bev.view(n, c * d, h, w)
-        r = _run_dn(e.rv, mid, *args)
+        r = _run_dn(e.rv, mid, *args, **pr)
         rv = od.to_dense_dn(r.feat, r.idx, r.n, r.batch, r.shape)
         n, c, d, h, w = rv.shape
         rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)
@@ -380,8 +382,13 @@ class FusedBackbone:
 
     HEADROOM = 1.125      # capacity = observed count x this, rounded up to 1024 rows
 
-    def __init__(self, module, dtype=torch.float32, eager=False, dispatch=None):
+    def __init__(self, module, dtype=torch.float32, eager=False, dispatch=None, f32_products=None):
         dev = next(module.parameters()).device
+        # fp32 matrix arithmetic of this engine's conv calls (0 / 6 / 9, include/vx_abi.h), carried in every call's
+        # flags; None = whatever the library default is when a step is issued (then part of the plan key)
+        if f32_products not in (None, 0, 6, 9):
+            raise ValueError("f32_products must be None, 0, 6 or 9")
+        self.f32_products = f32_products
         self.dev = dev
         self.kind = type(module).__name__
         self.dtype = dtype
@@ -452,7 +459,10 @@ class FusedBackbone:
         need = [rb.n_out for key, rb in st.cache.items() if key[0] == "conv"]
         return int(coords.shape[0]), need
 
-    def _build_plan(self, gen, frames, grid, old=None):
+    def _products(self):
+        return self.f32_products if self.f32_products is not None else int(ops.L.lib().vx_spconv_get_f32_products())
+
+    def _build_plan(self, gen, frames, grid, old=None, products=None):
         """Capacities from an eager geometry pass over these clouds (exact counts, with its host syncs: paid once
         per plan), never below those of the plan being replaced."""
         need_rows, need = self._probe(gen, frames, grid)
@@ -464,7 +474,8 @@ class FusedBackbone:
             caps = [max(a, b) for a, b in zip(caps, old.caps)]
         if old is not None:
             old.close()                # its graph and pool go before the new plan allocates and captures
-        plan = FramePlan(self._compiled, gen, len(frames), grid, cap_points, cap_rows, caps, frames[0].device)
+        plan = FramePlan(self._compiled, gen, len(frames), grid, cap_points, cap_rows, caps, frames[0].device,
+                         products=products)
         plan.stage(frames)
         return plan.capture() if self.dispatch == "graph" else plan
 
@@ -477,12 +488,14 @@ class FusedBackbone:
             return self(mean, coords, len(frames), grid)
         if any(f.shape[0] > gen._max_voxels for f in frames) or not 1 <= len(frames) <= 64:
             return self.eager_twin().forward_frames(gen, frames, grid)     # max_voxels truncation: per-frame calls
-        # a captured graph holds the kernels chosen when it was recorded: the fp32 matrix arithmetic is part of the key
-        key = (id(gen), len(frames), tuple(grid), int(ops.L.lib().vx_spconv_get_f32_products()))
+        # the fp32 matrix arithmetic is an argument of every conv call of a plan (never read from the process default
+        # at replay time), hence part of the key
+        products = self._products()
+        key = (id(gen), len(frames), tuple(grid), products)
         plan = self._plans.get(key)
         points = sum(int(f.shape[0]) for f in frames)
         if plan is None or points > plan.cap_points:
-            plan = self._plans[key] = self._build_plan(gen, frames, grid, plan)
+            plan = self._plans[key] = self._build_plan(gen, frames, grid, plan, products)
         stream = torch.cuda.current_stream(plan.dev)
         for attempt in range(2):
             plan.stage(frames)
@@ -492,7 +505,7 @@ class FusedBackbone:
                 return plan.out
             # some count exceeded its capacity (rows were dropped, so the counts after it are not reliable either):
             # size a new plan from an exact geometry pass over THIS input and run again
-            plan = self._plans[key] = self._build_plan(gen, frames, grid, plan)
+            plan = self._plans[key] = self._build_plan(gen, frames, grid, plan, products)
         raise ops.L.VxError("FramePlan: a plan sized from this very input overflowed")
 
     # ---- per-layer path ------------------------------------------------------------------------------------
@@ -506,18 +519,19 @@ class FusedBackbone:
         if self.kind == "MultiViewBackbone":
             _run(self.bev, geo, geom_only=True)
             _run(self.rv, geo, geom_only=True)
-        mid = _run(self.middle, st)
+        pr = dict(products=self._products())
+        mid = _run(self.middle, st, **pr)
         if self.kind == "SpMiddleResNetFHD":
             d = ops.to_dense(mid.feat, mid.idx, mid.batch, mid.shape, out=out)
             n, c, dd, h, w = d.shape
             return d.view(n, c * dd, h, w) if self.mode == "bev" else d
         if out is not None:
             raise NotImplementedError("out= is only supported for SpMiddleResNetFHD")
-        b = _run(self.bev, mid)
+        b = _run(self.bev, mid, **pr)
         bev = ops.to_dense(b.feat, b.idx, b.batch, b.shape)
         n, c, d, h, w = bev.shape
         bev = bev.view(n, c * d, h, w)
-        r = _run(self.rv, mid)
+        r = _run(self.rv, mid, **pr)
         rv = ops.to_dense(r.feat, r.idx, r.batch, r.shape)
         n, c, d, h, w = rv.shape
         rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)

@@ -330,15 +330,23 @@ def pack_weight(weight):
     return out
 
 
+def _arith(products):
+    try:
+        return L.ARITH_FLAG[products]
+    except KeyError:
+        raise ValueError("products must be None (library default), 0 (fp32 MFMA), 6 or 9 (bf16 plane products)")
+
+
 def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False,
-             sort_rows=False, wpack=None, compact=True, split_tail=True):
+             sort_rows=False, wpack=None, compact=True, split_tail=True, products=None):
     """features [n_in,Cin], weight [Cout,kz,ky,kx,Cin] (KRSC) -> [n_out,Cout]; fused epilogue
     relu?((acc + bias) * scale + shift + residual). sort_rows: run on the rulebook's mask-sorted
     row order (same bits out); wpack: packed weight copy -> barrier-free streaming-W kernel (fp32).
     Both are OFF by default: measured on MI355X they only pay together, on the
     sparse strided layers, and the sort costs what they save. compact=False forces the row-stationary
     kernels where the library would pick the per-offset compaction kernel (fp32, Cin <= 64); split_tail=False
-    launches the row-stationary kernel's plain grid (bitwise the same output, for A/B timing and tests)."""
+    launches the row-stationary kernel's plain grid (bitwise the same output, for A/B timing and tests).
+    products: fp32 matrix arithmetic of THIS call (0 / 6 / 9, include/vx_abi.h); None = the library default."""
     _need_gpu(features, "features")
     if features.dtype not in _DT:
         raise ValueError(f"unsupported feature dtype {features.dtype}")
@@ -369,14 +377,14 @@ def conv_fwd(features, weight, rb, bias=None, scale=None, shift=None, residual=N
         rc = L.lib().vx_spconv_fwd(_ptr(features), rb.n_in, cin, _ptr(weight), rb.kvol, cout, _ptr(nbr),
                                    max(rb.n_out, 1), rb.n_out, _ptr(bias), _ptr(scale), _ptr(shift),
                                    _ptr(residual), (L.VX_EPI_RELU if relu else 0) | (0 if compact else L.VX_CONV_NO_COMPACT)
-                                   | (0 if split_tail else L.VX_CONV_NO_SPLIT_TAIL),
+                                   | (0 if split_tail else L.VX_CONV_NO_SPLIT_TAIL) | _arith(products),
                                    _ptr(perm), _ptr(wpack),
                                    _ptr(out), _DT[features.dtype], _stream())
     L.check(rc, "vx_spconv_fwd")
     return out
 
 
-def conv_dgrad(grad_out, weight, rb):
+def conv_dgrad(grad_out, weight, rb, products=None):
     _need_gpu(grad_out, "grad_out")
     grad_out = grad_out.contiguous()
     cout, cin = weight.shape[0], weight.shape[-1]
@@ -385,7 +393,7 @@ def conv_dgrad(grad_out, weight, rb):
     tbl = rb.transpose()
     with torch.cuda.device(grad_out.device):
         rc = L.lib().vx_spconv_dgrad(_ptr(grad_out), rb.n_out, cout, _ptr(weight), rb.kvol, cin, _ptr(tbl),
-                                     max(rb.n_in, 1), rb.n_in, 1 if rb.subm else 0, _ptr(din),
+                                     max(rb.n_in, 1), rb.n_in, 1 if rb.subm else 0, _arith(products), _ptr(din),
                                      _DT[grad_out.dtype], _stream())
     L.check(rc, "vx_spconv_dgrad")
     return din
@@ -441,20 +449,28 @@ def from_dense(dense, indices, spatial_shape):
     return out
 
 
-def conv_wgrad(features, grad_out, rb, weight_shape):
-    """-> dW float32 with the KRSC shape of the weight."""
+def conv_wgrad(features, grad_out, rb, weight_shape, products=None, out=None):
+    """-> dW float32 with the KRSC shape of the weight. out: a contiguous float32 tensor of that shape to OVERWRITE
+    instead of allocating (e.g. the parameter's view into a flat gradient buffer)."""
     _need_gpu(features, "features")
     features = features.contiguous()
     grad_out = grad_out.contiguous()
     cout, cin = int(weight_shape[0]), int(weight_shape[-1])
     pairs, num = rb.pairs()
-    dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=features.device)
+    if out is None:
+        dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=features.device)
+    else:
+        if (out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != tuple(weight_shape)
+                or out.device != features.device):
+            raise ValueError("conv_wgrad: out must be a contiguous float32 tensor of the weight's shape on the same device")
+        dw = out
     lib = L.lib()
     wsb = lib.vx_spconv_wgrad_workspace_bytes(cin, cout, rb.kvol, rb.n_out)
     ws = _ws(wsb, features.device)
     with torch.cuda.device(features.device):
         rc = lib.vx_spconv_wgrad(_ptr(features), rb.n_in, cin, _ptr(grad_out), rb.n_out, cout, _ptr(pairs),
-                                 _ptr(num), rb.kvol, _ptr(dw), _DT[features.dtype], _ptr(ws), wsb, _stream())
+                                 _ptr(num), rb.kvol, _ptr(dw), _DT[features.dtype], _arith(products), _ptr(ws), wsb,
+                                 _stream())
     L.check(rc, "vx_spconv_wgrad")
     return dw
 

@@ -110,7 +110,7 @@ def rulebook_conv_dn(indices, n_in, batch_size, spatial_shape, ksize, stride, pa
     return RulebookDn(nbr, n_out, int(cap_out), kvol, out_idx, list(osh), rank)
 
 
-def conv_fwd_dn(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False):
+def conv_fwd_dn(features, weight, rb, bias=None, scale=None, shift=None, residual=None, relu=False, products=None):
     """features [cap_in, Cin] -> [rb.cap, Cout]; rows at and past the device count are left unwritten."""
     _need_gpu(features, "features")
     if features.dtype not in _DT or weight.dtype != features.dtype:
@@ -127,7 +127,8 @@ def conv_fwd_dn(features, weight, rb, bias=None, scale=None, shift=None, residua
     with torch.cuda.device(features.device):
         rc = L.lib().vx_spconv_fwd_dn(_ptr(features), features.shape[0], cin, _ptr(weight), rb.kvol, cout,
                                       _ptr(rb.nbr), rb.cap, _ptr(rb.n_out), rb.cap, _ptr(bias), _ptr(scale),
-                                      _ptr(shift), _ptr(residual), L.VX_EPI_RELU if relu else 0, _ptr(out),
+                                      _ptr(shift), _ptr(residual),
+                                      (L.VX_EPI_RELU if relu else 0) | L.ARITH_FLAG[products], _ptr(out),
                                       _DT[features.dtype], _stream())
     L.check(rc, "vx_spconv_fwd_dn")
     return out
