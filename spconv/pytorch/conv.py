@@ -20,10 +20,17 @@ class _SparseConvFn(torch.autograd.Function):
     """out = conv(features, weight) + bias over a rulebook; dgrad/wgrad are the libvx kernels."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, bias_grad_zero=False):
+    def forward(ctx, features, weight, bias, rb, bias_grad_zero=False, sink_w=None, sink_b=None):
         ctx.rb = rb
         ctx.has_bias = bias is not None
         ctx.bias_grad_zero = bias_grad_zero
+        # gradient sinks (vista_amd.train.GradBuckets): the parameter's slice of the flat gradient buffer, written by
+        # the wgrad kernel itself instead of through autograd's accumulate add. A parameter used more than once in a
+        # forward pass falls back to autograd's accumulation.
+        ctx.sink_w, ctx.sink_b = sink_w, sink_b
+        for sk in (sink_w, sink_b):
+            if sk is not None:
+                sk.uses += 1
         ctx.save_for_backward(features, weight)
         return vx.conv_fwd(features, weight, rb, bias=bias)
 
@@ -36,12 +43,23 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             din = vx.conv_dgrad(grad_out, weight, rb)
         if ctx.needs_input_grad[1]:
-            dw = vx.conv_wgrad(features, grad_out, rb, weight.shape).to(weight.dtype)
+            sk = ctx.sink_w
+            if sk is not None and sk.uses == 1 and weight.dtype == torch.float32:
+                vx.conv_wgrad(features, grad_out, rb, weight.shape, out=sk.view)
+                sk.done()
+            else:
+                dw = vx.conv_wgrad(features, grad_out, rb, weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # in front of a batch-statistics norm the column sums of grad_out are zero by construction (the norm
             # subtracts the batch mean, SyncBatchNorm the global one): write the zeros, skip the reduction
-            db = grad_out.new_zeros(grad_out.shape[1]) if ctx.bias_grad_zero else grad_out.sum(0)
-        return din, dw, db, None, None
+            sk = ctx.sink_b
+            if sk is not None and sk.uses == 1:
+                if not ctx.bias_grad_zero:
+                    torch.sum(grad_out, 0, out=sk.view)
+                sk.done()                              # (the flat buffer was zeroed at the start of the step)
+            else:
+                db = grad_out.new_zeros(grad_out.shape[1]) if ctx.bias_grad_zero else grad_out.sum(0)
+        return din, dw, db, None, None, None, None
 
 
 def convert_weight(w, layout):
@@ -141,7 +159,10 @@ class SparseConvolution(SparseModule):
         rb = self._rulebook(input)
         weight = self.weight if self.weight.dtype == feats.dtype else self.weight.to(feats.dtype)
         norm = self.norm_after
-        out_feats = _SparseConvFn.apply(feats, weight, self.bias, rb, norm is not None and norm.training)
+        direct = weight is self.weight and torch.is_grad_enabled()
+        out_feats = _SparseConvFn.apply(feats, weight, self.bias, rb, norm is not None and norm.training,
+                                        getattr(self.weight, "_vx_grad_sink", None) if direct else None,
+                                        getattr(self.bias, "_vx_grad_sink", None) if direct and self.bias is not None else None)
         out = SparseConvTensor(out_feats, input.indices if self.subm else rb.out_indices,
                                input.spatial_shape if self.subm else rb.out_shape, input.batch_size,
                                input.grid, input.voxel_num, input.indice_dict, input.benchmark)

@@ -100,6 +100,23 @@ def test_sync_batchnorm_sum_exchange_gives_global_statistics():
     assert torch.allclose(var, x.var(0, unbiased=False), rtol=1e-10, atol=1e-12)
 
 
+class _SyncSum(torch.autograd.Function):
+    """Stand-in for FusedBatchNorm1d(sync=True) on the CPU: identity forward, and in BACKWARD an all-reduce of a small
+    vector on the default process group -- the collective SyncBatchNorm issues between a layer's gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, log):
+        ctx.log = log
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = g.sum(0)
+        dist.all_reduce(t)
+        ctx.log.append(t.clone())
+        return g, None
+
+
 def _bucket_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -108,11 +125,13 @@ def _bucket_worker(rank, world, port, q):
 
     def make():
         torch.manual_seed(0)
-        return torch.nn.ModuleDict(dict(a=torch.nn.Linear(6, 8), b=torch.nn.Linear(8, 5), c=torch.nn.Linear(5, 3),
-                                        unused=torch.nn.Linear(4, 4)))
+        # `unused` first: it comes LAST in backward order, so the buckets before its own complete on every rank
+        return torch.nn.ModuleDict(dict(unused=torch.nn.Linear(4, 4), a=torch.nn.Linear(6, 8), b=torch.nn.Linear(8, 5),
+                                        c=torch.nn.Linear(5, 3)))
 
-    def loss_of(net, x):
-        y = net["c"](torch.relu(net["b"](torch.relu(net["a"](x)))))
+    def loss_of(net, x, log):
+        y = torch.relu(_SyncSum.apply(net["a"](x), log))
+        y = net["c"](torch.relu(_SyncSum.apply(net["b"](y), log)))
         if rank == 1:                       # only rank 1 touches `unused`: on rank 0 its gradient is None
             y = y + net["unused"](x[:, :4]).sum() * 0.1
         return (y ** 2).sum()
@@ -120,24 +139,33 @@ def _bucket_worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(5, 6, generator=g)
     flat_net, bucket_net = make(), make()
-    loss_of(flat_net, x).backward()
+    sync_ref, sync_got = [], []
+    loss_of(flat_net, x, sync_ref).backward()
     assert (flat_net["unused"].weight.grad is None) == (rank == 0)
     nbytes = allreduce_grads_flat(list(flat_net.parameters()), dist, world)
     gb = GradBuckets(bucket_net.named_parameters(), 3, dist, world)
-    for _ in range(2):                      # twice: the second step starts from zero() with the views still attached
+    logs = []
+    for _ in range(3):                      # the later steps start from zero() with the views still attached
         gb.zero()
-        loss_of(bucket_net, x).backward()
+        sync_got.clear()
+        loss_of(bucket_net, x, sync_got).backward()
         assert gb.finish() == nbytes
+        logs.append(list(gb.log))
+    names = [n for n, _ in flat_net.named_parameters()]
     flat = torch.cat([p.grad.reshape(-1) for p in flat_net.parameters()])
-    buck = torch.cat([p.grad.reshape(-1) for p in bucket_net.parameters()])
-    q.put((rank, flat.numpy().tobytes(), buck.numpy().tobytes(), list(gb.log), len(gb.bounds)))
+    buck = torch.cat([dict(bucket_net.named_parameters())[n].grad.reshape(-1) for n in names])
+    same_sync = all(torch.equal(u, v) for u, v in zip(sync_ref, sync_got)) and len(sync_got) == 2
+    q.put((rank, flat.numpy().tobytes(), buck.numpy().tobytes(), logs, len(gb.bounds), gb.hook_limit, same_sync))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_bucketed_exchange_equals_flat_exchange_bitwise_with_a_missing_gradient():
     """GradBuckets (gradients as views of one flat buffer, buckets reduced as they complete) against the single flat
-    all-reduce: identical bits on both ranks, although rank 0 has no gradient for one parameter."""
+    all-reduce: identical bits on both ranks, although rank 0 has no gradient for one parameter AND the backward pass
+    issues SyncBatchNorm-style collectives on the same process group between the layers: every rank fires
+    every bucket at the same point of its backward pass -- nothing from hooks on the first step, then exactly the
+    buckets that every rank completes."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -149,9 +177,12 @@ def test_bucketed_exchange_equals_flat_exchange_bitwise_with_a_missing_gradient(
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, flat, buck, log, nb in res:
-        assert flat == buck and len(flat) > 0
-        assert nb >= 2 and [b for b, _ in log] == list(range(nb))      # same order of collectives on every rank
+    for rank, flat, buck, logs, nb, limit, same_sync in res:
+        assert flat == buck and len(flat) > 0 and same_sync
+        assert nb == 3 and limit == 2                  # the last bucket holds `unused`: incomplete on rank 0
+        for log in logs:
+            assert [b for b, _ in log] == list(range(nb))
+        assert [why for _, why in logs[0]] == ["finish"] * nb                       # first step: agreement only
+        assert [why for _, why in logs[1]] == ["hook", "hook", "finish"] == [why for _, why in logs[2]]
     assert res[0][1] == res[1][1]
-    # rank 0 never saw a gradient for `unused`: its bucket cannot complete from hooks there and is sent by finish()
-    assert any(why == "finish" for _, why in res[0][3]) and all(why == "hook" for _, why in res[1][3])
+    assert res[0][3] == res[1][3]                       # the same firing points on both ranks, step by step

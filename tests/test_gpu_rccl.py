@@ -35,7 +35,11 @@ def test_training_step_through_rccl_world1_equals_single_process_step():
         losses = [float(train_step(net, opt, mean, coords, 2, grid, dist if use_dist else None, 1, gb)) for _ in range(2)]
         return losses, [p.detach().clone() for p in net.parameters()], gb
 
-    ref_losses, ref_params, _ = run(False, True)
+    ref_losses, ref_params, gb0 = run(False, True)
+    # every gradient of the step was written straight into its slice of the flat buffer: 21 conv weights, 16 block
+    # biases, 21 x (gamma, beta) of the fused BatchNorms -- no accumulate adds (the un-bucketed runs below go through
+    # autograd's accumulation and must give the same bits)
+    assert gb0.direct == len(gb0.params) == 21 + 16 + 42
     with tempfile.TemporaryDirectory() as td:
         dist.init_process_group("nccl", init_method=f"file://{os.path.join(td, 'rdv')}", rank=0, world_size=1)
         try:

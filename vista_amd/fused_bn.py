@@ -34,7 +34,7 @@ def _all_reduce_sum(t, group):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, mod):
+    def forward(ctx, x, gamma, beta, residual, mod, sinks=None):
         x = x.contiguous()
         c = x.shape[1]
         sums = ops.bn_stats(x)
@@ -45,6 +45,10 @@ class _BatchNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, invstd, mask, sums[2 * c:])
         ctx.mod = mod
         ctx.has_res = residual is not None
+        ctx.sinks = sinks
+        if sinks is not None:
+            sinks[0].uses += 1
+            sinks[1].uses += 1
         return y
 
     @staticmethod
@@ -53,7 +57,10 @@ class _BatchNormFn(torch.autograd.Function):
         mod = ctx.mod
         c = x.shape[1]
         dy = dy.contiguous()
-        sums, pgrads = ops.bn_bwd_reduce(dy, x, mask, mean, invstd)
+        direct = ctx.sinks is not None and ctx.sinks[0].uses == 1 and ctx.sinks[1].uses == 1 \
+            and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        pg_out = ctx.sinks[1].gb.flat[ctx.sinks[1].lo:ctx.sinks[1].lo + 2 * c] if direct else None
+        sums, pgrads = ops.bn_bwd_reduce(dy, x, mask, mean, invstd, pg_out=pg_out)
         if mod.sync:
             mod.reduce_sums(sums)
         want_dres = ctx.has_res and ctx.needs_input_grad[3]
@@ -61,7 +68,11 @@ class _BatchNormFn(torch.autograd.Function):
                                     want_dres=want_dres and mask is not None)
         if want_dres and mask is None:
             dres = dy            # no ReLU between the add and the output: the residual branch sees dy itself
-        return dx, pgrads[c:], pgrads[:c], dres, None
+        if direct:
+            ctx.sinks[1].done()
+            ctx.sinks[0].done()
+            return dx, None, None, dres, None, None
+        return dx, pgrads[c:], pgrads[:c], dres, None, None
 
 
 class FusedBatchNorm1d(nn.BatchNorm1d):
@@ -107,7 +118,14 @@ class FusedBatchNorm1d(nn.BatchNorm1d):
                 y = y + residual
             return F.relu(y) if self.relu else y
         self.num_batches_tracked.add_(1)
-        return _BatchNormFn.apply(x, self.weight, self.bias, residual, self)
+        # gradient sinks of (gamma, beta) (vista_amd.train.GradBuckets): when beta and gamma sit next to each other in
+        # the flat gradient buffer, in that order, vx_bn_bwd_reduce writes its {d beta, d gamma} vector straight there
+        sinks = None
+        sg, sb = getattr(self.weight, "_vx_grad_sink", None), getattr(self.bias, "_vx_grad_sink", None)
+        if (sg is not None and sb is not None and torch.is_grad_enabled()
+                and sb.view.data_ptr() + 4 * x.shape[1] == sg.view.data_ptr()):
+            sinks = (sg, sb)
+        return _BatchNormFn.apply(x, self.weight, self.bias, residual, self, sinks)
 
 
 class FusedSparseBasicBlock(spconv.SparseModule):

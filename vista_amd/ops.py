@@ -549,8 +549,9 @@ def bn_apply(x, mean, invstd, gamma=None, beta=None, residual=None, relu=False):
     return y, mask
 
 
-def bn_bwd_reduce(dy, x, mask, mean, invstd):
-    """-> (sums f64[2c] = (sum g, sum g*xhat), param_grads f32[2c] = (d beta, d gamma) of this rank)."""
+def bn_bwd_reduce(dy, x, mask, mean, invstd, pg_out=None):
+    """-> (sums f64[2c] = (sum g, sum g*xhat), param_grads f32[2c] = (d beta, d gamma) of this rank). pg_out: a contiguous
+    float32[2c] tensor to OVERWRITE with the parameter gradients instead of allocating one."""
     dy, x = _bn_check(dy, "dy"), _bn_check(x, "x")
     if dy.shape != x.shape:
         raise ValueError("dy must match x")
@@ -558,7 +559,12 @@ def bn_bwd_reduce(dy, x, mask, mean, invstd):
     if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != n * c // 8 or not mask.is_cuda):
         raise ValueError("mask must be the uint8[n*c/8] tensor bn_apply returned")
     sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
-    pg = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    if pg_out is None:
+        pg = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    else:
+        if pg_out.dtype != torch.float32 or pg_out.numel() != 2 * c or not pg_out.is_contiguous() or pg_out.device != x.device:
+            raise ValueError("pg_out must be a contiguous float32[2c] tensor on x's device")
+        pg = pg_out
     lib = L.lib()
     wsb = lib.vx_bn_workspace_bytes(c)
     ws = _ws(wsb, x.device)

@@ -63,6 +63,21 @@ def allreduce_grads_flat(params, dist=None, world=1):
     return flat.numel() * flat.element_size()
 
 
+class _GradSink:
+    """A parameter's slice of the flat gradient buffer, for backward functions that write a gradient in place instead
+    of returning it (spconv's wgrad, the fused BatchNorm's parameter gradients): `view` is the destination, done()
+    reports the gradient complete (what the post-accumulate hook reports for gradients that come through autograd),
+    `uses` counts the parameter's uses in the current forward pass (a direct write is only valid for a single use)."""
+    __slots__ = ("gb", "name", "lo", "view", "uses")
+
+    def __init__(self, gb, name, lo, view):
+        self.gb, self.name, self.lo, self.view, self.uses = gb, name, lo, view, 0
+
+    def done(self):
+        self.gb.direct += 1
+        self.gb._arrived(self.name)
+
+
 class GradBuckets:
     """The gradient exchange of the data-parallel step (DDP's job at det3d/torchie/apis/train.py:302-308).
 
@@ -73,7 +88,19 @@ class GradBuckets:
     under the "nccl" backend), so the exchange of the deep stages overlaps the dgrad/wgrad kernels of the shallower
     ones. finish() issues whatever did not fire (parameters that got no gradient this step still take part, as
     zeros, so every rank reduces the same slices), waits, and divides by the world size.
-    Bucketed and single-bucket exchanges give identical sums element by element."""
+    Bucketed and single-bucket exchanges give identical sums element by element.
+
+    Collective ORDER across ranks. These all-reduces share the process group with the SyncBatchNorm sum exchanges of
+    the backward pass, so every rank must issue them at the same points of its backward pass. A bucket fires from a
+    hook only if it -- and every bucket before it -- is complete on EVERY rank: the first step fires nothing from
+    hooks, and its finish() all-reduces (MIN) the number of leading buckets this rank completed; from then on exactly
+    those buckets fire from hooks, on every rank at the same gradient, and the rest go out from finish(), again on
+    every rank. The set of parameters that receive a gradient must therefore not change from step to step (the
+    assumption DistributedDataParallel makes with find_unused_parameters=False); call reprobe() when it does.
+
+    Direct writes: every parameter carries a `_vx_grad_sink` (its slice of the buffer); spconv's wgrad and the fused
+    BatchNorm backward write their result there and report it complete, which removes autograd's accumulate add
+    (88 small kernels per step of SpMiddleResNetFHD)."""
 
     def __init__(self, named_params, n_buckets=4, dist=None, world=1):
         named = [(n, p) for n, p in named_params if p.requires_grad]
@@ -94,6 +121,7 @@ class GradBuckets:
         for i, (name, p) in enumerate(order):
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            p._vx_grad_sink = _GradSink(self, name, off, p.grad)
             off += n
             cur.append(name)
             if (off - start >= target and len(self.bounds) < n_buckets - 1) or i == len(order) - 1:
@@ -106,12 +134,33 @@ class GradBuckets:
                 self.bucket_of[name] = b
         self.params = dict(order)
         self.arrived = [0] * len(self.bounds)
+        self.seen = set()
+        self.direct = 0                                       # gradients written in place this step (no accumulate add)
         self.fired = [False] * len(self.bounds)
         self.next = 0                                         # next bucket to send
         self.works = []
         self.log = []                                         # (bucket, "hook" | "finish") in firing order
+        # leading buckets that may fire from hooks: all of them on one rank, none until finish() has agreed on a
+        # number otherwise (class docstring, "Collective ORDER")
+        self.hook_limit = len(self.bounds) if (dist is None or self.world <= 1) else None
         for name, p in order:
             p.register_post_accumulate_grad_hook(self._make_hook(name, p))
+
+    def reprobe(self):
+        """Forget which buckets may fire from hooks: the next step sends everything from finish() and agrees anew."""
+        if self.dist is not None and self.world > 1:
+            self.hook_limit = None
+
+    def _arrived(self, name):
+        """A parameter's gradient is complete in the flat buffer (hook or direct write)."""
+        if name in self.seen:
+            return
+        self.seen.add(name)
+        self.arrived[self.bucket_of[name]] += 1
+        limit = self.hook_limit or 0
+        # buckets go out strictly in index order, and only those that every rank completes from its hooks
+        while self.next < limit and self.arrived[self.next] == len(self.members[self.next]):
+            self._fire(self.next, "hook")
 
     def _make_hook(self, name, p):
         b = self.bucket_of[name]
@@ -124,11 +173,8 @@ class GradBuckets:
                 if g is not None:
                     self.flat[lo:lo + param.numel()].copy_(g.reshape(-1))
                 param.grad = self.flat[lo:lo + param.numel()].view_as(param)
-            self.arrived[b] += 1
-            # buckets go out strictly in index order, so every rank issues the same sequence of collectives even
-            # when some rank never completes a bucket from its hooks (a parameter without a gradient there)
-            while self.next < len(self.bounds) and self.arrived[self.next] == len(self.members[self.next]):
-                self._fire(self.next, "hook")
+                param._vx_grad_sink.view = param.grad
+            self._arrived(name)
         return hook
 
     def _fire(self, b, why):
@@ -146,11 +192,23 @@ class GradBuckets:
         """Start of a step (instead of optimizer.zero_grad): one fill; the .grad views stay attached."""
         self.flat.zero_()
         self.arrived = [0] * len(self.bounds)
+        self.seen = set()
         self.fired = [False] * len(self.bounds)
-        self.works, self.log, self.next = [], [], 0
+        self.works, self.log, self.next, self.direct = [], [], 0, 0
+        for p in self.params.values():
+            p._vx_grad_sink.uses = 0
 
     def finish(self):
         """After backward: reduce the buckets that did not fire, wait for all of them, average."""
+        if self.hook_limit is None:
+            # first step under a process group: how many leading buckets did EVERY rank complete? (one tiny MIN
+            # all-reduce, issued here by every rank -- after backward, hence after every SyncBatchNorm exchange)
+            k = 0
+            while k < len(self.bounds) and self.arrived[k] == len(self.members[k]):
+                k += 1
+            t = torch.tensor([k], dtype=torch.int64, device=self.flat.device if self.dist.get_backend() == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            self.hook_limit = int(t.item())
         while self.next < len(self.bounds):
             self._fire(self.next, "finish")
         for w in self.works:
