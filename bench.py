@@ -30,7 +30,6 @@ sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense matrix peak (the chip holds a lower clock under bf16 load)
-PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -206,6 +205,8 @@ def dominant_kernel_roofline(timing, dtype):
                     "peak_basis": f"bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {products} plane products "
                                   "per fp32 product (algorithmic fp32 flops)",
                     "frac_of_fp32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(f"f32_split{products}"),
+                    "limiter": "board power: matrix pipe and L2->LDS fill overlap in cycles but the clock drops from 2.35 to "
+                               "1.93 GHz when both run (DESIGN.md section 4, round-3 ablations)",
                     "kernel": f"spconv_w8s body, <128,128,{products}> (SubMConv3d 128->128, k=3; fp32 in/out/accumulate)",
                     **common}
         # fp32 MFMA: intensity Cout/2 = 64 flop per gathered byte -> MFMA-bound (157.3 TFLOP/s fp32 matrix peak)
@@ -217,9 +218,20 @@ def dominant_kernel_roofline(timing, dtype):
     nbytes = np.array([p_ * 128 * 2 + t["rb"].n_out * 128 * 2 + 27 * 128 * 128 * 2 + p_ * 8
                        for t, p_ in zip(sel, [pairs[id(t["rb"])] for t in sel])], dtype=np.float64)
     gbs = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
-    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-            "traffic": pmc_traffic("bf16"), "kernel": "spconv_w8 body, <bf16,128,128> (SubMConv3d 128->128, k=3)",
-            "bytes_per_launch": float(nbytes.mean()), **common}
+    traffic = pmc_traffic("bf16")
+    out = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+           "traffic": traffic, "kernel": "spconv_w8 body, <bf16,128,128> (SubMConv3d 128->128, k=3)",
+           "bytes_per_launch": float(nbytes.mean()), **common,
+           # `achieved` prices the ALGORITHMIC gather bytes; most of them are L2 hits (rows are re-used across offsets
+           # and tiles). What the counters say about the two real ceilings:
+           "frac_of_bf16_mfma_peak": tflops / PEAK_BF16_MFMA_TFLOPS,
+           "limiter": "L2->CU fill (on-chip): neither HBM nor the matrix pipe. The gathered rows, their zero rows and the "
+                      "W chunk re-read by every 256-row tile arrive at ~25 B/clk/CU (DESIGN.md section 4)"}
+    if traffic:
+        real = traffic / (float(ms.mean()) * 1e-3) / 1e9
+        out["hbm_counter_GB_per_s"] = real
+        out["frac_of_hbm_peak_from_counters"] = real / PEAK_HBM_GBS
+    return out
 
 
 def phase_report(timing, steps, batch, geometry="FHD"):
@@ -266,7 +278,7 @@ def phase_report(timing, steps, batch, geometry="FHD"):
 def pmc_traffic(dtype):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if absent."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", name)))
             return d["dominant_kernel"][dtype]["hbm_bytes_per_launch"]
@@ -278,10 +290,13 @@ def pmc_traffic(dtype):
 def pmc_phase_traffic(geometry, batch):
     """{phase: HBM bytes per frame} of the hash / rulebook / dense kernels from profiles/r02_pmc_hash.json."""
     try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_hash.json")))
-        return d["per_frame_bytes"][f"{geometry}_b{batch}"]
+        for name in ("r03_pmc_hash.json", "r02_pmc_hash.json"):
+            path = os.path.join(REPO, "profiles", name)
+            if os.path.exists(path):
+                return json.load(open(path))["per_frame_bytes"][f"{geometry}_b{batch}"]
     except Exception:
-        return {}
+        pass
+    return {}
 
 
 def init_dist(a):
