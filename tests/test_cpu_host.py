@@ -210,3 +210,23 @@ def test_fuse_for_training_keeps_parameters_and_keys():
     assert torch.equal(f(x, residual=r), torch.relu(bn(x) + r))
     with pytest.raises(ValueError):
         FusedBatchNorm1d.from_bn(torch.nn.BatchNorm1d(16, affine=False))
+
+
+def test_vx_trace_names_every_abi_call_before_it_runs(tmp_path):
+    """VX_TRACE=1: one stderr line per C-ABI call, written BEFORE the call (so a fatal failure below Python names it);
+    size / version queries are not traced. Runs in a child process (the setting is read when vista_amd._lib loads)."""
+    import os
+    import subprocess
+    import sys
+    code = ("from vista_amd import _lib as L\n"
+            "lib = L.lib()\n"
+            "assert lib.vx_version() >= 1\n"
+            "assert lib.vx_voxelize_workspace_bytes(1000) > 0\n"
+            "assert lib.vx_spconv_get_f32_products() in (0, 6, 9)\n"
+            "assert lib.vx_fill(None, 0, 0, None) == 0\n"        # a traced call that needs no GPU: zero bytes
+            "L.trace('marker')\n")
+    env = dict(os.environ, VX_TRACE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stderr.splitlines() if ln.startswith("[vx] ")]
+    assert lines == ["[vx] vx_fill", "[vx] marker"]          # queries and settings are not launches

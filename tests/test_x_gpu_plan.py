@@ -270,3 +270,36 @@ def test_plan_error_word_is_not_sticky(dev):
         plan.overflow()
     assert torch.equal(_bits(eng.forward_frames(gen, fr, grid)), _bits(ref))     # cleared inside the step
     assert next(iter(eng._plans.values())) is plan
+
+
+def test_plan_soak_random_frame_sets(dev):
+    """Forty random frame sets (1-3 frames of 1-4 sweeps, empty-ish to large) through ONE graph engine and one queued
+    engine: every result bitwise the eager path's, plans re-used / re-planned / rebuilt as sizes move, nothing leaks
+    (at most one plan per batch size and arithmetic stays open)."""
+    from vista_amd.synth import GEOMETRIES, grid_size, lidar_cloud
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES["SMALL"]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    g_eng = _engine("SpMiddleResNetFHD", dev, torch.float32, "graph")
+    q_eng = _engine("SpMiddleResNetFHD", dev, torch.bfloat16, "queued")
+    eager32, eager16 = g_eng.eager_twin(), q_eng.eager_twin()
+    rng = np.random.default_rng(2024)
+    clouds = {}
+    for it in range(40):
+        nfr = int(rng.integers(1, 4))
+        fr = []
+        for _ in range(nfr):
+            seed, sweeps = int(rng.integers(0, 6)), int(rng.integers(1, 5))
+            if (seed, sweeps) not in clouds:
+                clouds[seed, sweeps] = torch.from_numpy(lidar_cloud(seed=seed, sweeps=sweeps)).to(dev)
+            c = clouds[seed, sweeps]
+            keep = int(rng.integers(max(1, c.shape[0] // 8), c.shape[0] + 1))      # a random prefix: sizes move a lot
+            fr.append(c[:keep].contiguous())
+        for eng, ref in ((g_eng, eager32), (q_eng, eager16)):
+            got, want = eng.forward_frames(gen, fr, grid), ref.forward_frames(gen, fr, grid)
+            assert torch.equal(_bits(got), _bits(want)), it
+    assert len(g_eng._plans) <= 3 and len(q_eng._plans) <= 3
+    assert all(not p.closed for p in g_eng._plans.values())
+    g_eng.close()
+    q_eng.close()
