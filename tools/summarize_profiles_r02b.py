@@ -4,11 +4,15 @@ kernels in the default split-bf16 arithmetic and on the fp32 MFMA)."""
 import csv
 import glob
 import json
+import os
 import re
 import statistics as st
 
 G = "gpurun_out"
-T = "r02b"
+# round 3 re-ran the counter passes only (tools/run_pmc_r03.sh): VX_PROF_TAG=r03 VX_PROF_PMC_ONLY=1 VX_PROF_OUT=profiles/r03_pmc_summary.json
+T = os.environ.get("VX_PROF_TAG", "r02b")
+PMC_ONLY = bool(os.environ.get("VX_PROF_PMC_ONLY"))
+OUT = os.environ.get("VX_PROF_OUT", "profiles/r02_pmc_summary.json")
 
 
 def short(n):
@@ -31,6 +35,8 @@ def kstats(tag, dst, cmd, note):
 
 
 ARITH = "default fp32 arithmetic = 6 split-bf16 plane products"
+if PMC_ONLY:
+    kstats = lambda *a, **k: None
 kstats("f32_b8", "profiles/r02_bench_b8_fp32_kernel_stats.csv", "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants",
        f"{ARITH}; 3 warm-up + 10 timed steps as one captured HIP graph each, a probe pass and 1 + 10 instrumented eager steps: 25 steps of kernels")
 kstats("f32_b1", "profiles/r02_bench_b1_fp32_kernel_stats.csv", "bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-variants",
@@ -116,4 +122,4 @@ for mode, ((a, b, c3), keys) in specs.items():
         print(slot, mode, f"hbm {v['hbm_bytes_per_launch'] / 1e9:.2f} GB  mfma_util {v['mfma_util']:.3f}  l2 {v['l2_hit_rate']:.3f}  "
               f"clock {v['clock_GHz_under_pmc']:.2f} GHz  lds_conflict {v['lds_bank_conflict_cycles']:.0f}  "
               f"{v['algorithmic_TFLOPs_under_pmc']:.1f} TF  {v['algorithmic_GBps_under_pmc']:.0f} GB/s")
-json.dump(res, open("profiles/r02_pmc_summary.json", "w"), indent=1)
+json.dump(res, open(OUT, "w"), indent=1)
