@@ -40,15 +40,27 @@ class _SparseConvFn(torch.autograd.Function):
         rb = ctx.rb
         grad_out = grad_out.contiguous()
         din = dw = db = None
-        if ctx.needs_input_grad[0]:
-            din = vx.conv_dgrad(grad_out, weight, rb)
         if ctx.needs_input_grad[1]:
             sk = ctx.sink_w
             if sk is not None and sk.uses == 1 and weight.dtype == torch.float32:
-                vx.conv_wgrad(features, grad_out, rb, weight.shape, out=sk.view)
+                side = sk.gb.wgrad_stream(features.device)
+                if side is None:
+                    vx.conv_wgrad(features, grad_out, rb, weight.shape, out=sk.view)
+                else:
+                    # wgrad and dgrad of a layer both start from grad_out and nothing downstream reads the weight
+                    # gradient before the exchange: wgrad goes to the buckets' side stream (issued BEFORE dgrad, so it
+                    # waits for grad_out only) and runs beside the dgrad / BatchNorm kernels of the main stream
+                    held = (features, grad_out) + tuple(rb.pairs())   # pair list built once, on the main stream
+                    side.wait_stream(torch.cuda.current_stream(features.device))
+                    with torch.cuda.stream(side):
+                        vx.conv_wgrad(features, grad_out, rb, weight.shape, out=sk.view)
+                    for t in held:          # freed by autograd / with the rulebook while the side stream may still read them
+                        t.record_stream(side)
                 sk.done()
             else:
                 dw = vx.conv_wgrad(features, grad_out, rb, weight.shape).to(weight.dtype)
+        if ctx.needs_input_grad[0]:
+            din = vx.conv_dgrad(grad_out, weight, rb)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # in front of a batch-statistics norm the column sums of grad_out are zero by construction (the norm
             # subtracts the batch mean, SyncBatchNorm the global one): write the zeros, skip the reduction

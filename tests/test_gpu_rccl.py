@@ -57,3 +57,44 @@ def test_training_step_through_rccl_world1_equals_single_process_step():
             assert allreduce_grads_flat([p], dist, 1) == 32 and torch.equal(p.grad, t)
         finally:
             dist.destroy_process_group()
+
+
+def test_wgrad_side_stream_is_bitwise_the_single_stream_step(monkeypatch):
+    """GradBuckets puts the weight-gradient kernels on a second stream beside dgrad / BatchNorm backward (spconv's
+    backward, vista_amd/train.py). Two full-size FHD frames, three optimizer steps: parameters and the flat gradient
+    buffer must come out bit for bit as with VX_WGRAD_STREAM=0 -- the kernels are the same, only their streams
+    differ, so any difference would be a missing dependency (a gradient read before its wgrad finished, an input
+    freed and reused under the side stream)."""
+    from _fullsize_cases import _setup
+    from vista_amd import models
+    from vista_amd.fused_bn import fuse_for_training
+    from vista_amd.synth import backbone_state_dict
+    from vista_amd.train import GradBuckets, train_step
+    from vista_amd.voxel import voxelize_batch
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    gen, clouds, grid, _ = _setup("FHD", [0, 1], 10, dev)
+    frames = [torch.from_numpy(c).to(dev) for c in clouds]
+    sd = backbone_state_dict("SpMiddleResNetFHD")
+
+    def run(side):
+        monkeypatch.setenv("VX_WGRAD_STREAM", "1" if side else "0")
+        net = fuse_for_training(models.load_numpy_state_dict(models.SpMiddleResNetFHD(num_input_features=5), sd).to(dev).train())
+        opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+        gb = GradBuckets(net.named_parameters(), 4, None, 1)
+        assert gb.side_enabled == side
+        flats = []
+        for _ in range(3):
+            mean, coords, _ = voxelize_batch(gen, frames)
+            train_step(net, opt, mean, coords, len(frames), grid, None, 1, gb)
+            assert gb.side_used == side and gb.direct == len(gb.params)
+            flats.append(gb.flat.clone())
+        torch.cuda.synchronize()
+        return flats, [p.detach().clone() for p in net.parameters()]
+
+    f1, p1 = run(True)
+    f0, p0 = run(False)
+    for a, b in zip(f1, f0):
+        assert torch.equal(a, b) and float(a.abs().sum()) > 0
+    for a, b in zip(p1, p0):
+        assert torch.equal(a, b)

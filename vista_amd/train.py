@@ -12,6 +12,7 @@ when the backend is "nccl"; gloo in the CPU tests). The backbone holds ~2.7 M fp
 gradient lives in ONE flat buffer (GradBuckets): a handful of contiguous slices, deepest stage first, are
 reduced as soon as their gradients are complete, overlapping the remaining dgrad/wgrad kernels.
 """
+import os
 import time
 
 import numpy as np
@@ -143,8 +144,27 @@ class GradBuckets:
         # leading buckets that may fire from hooks: all of them on one rank, none until finish() has agreed on a
         # number otherwise (class docstring, "Collective ORDER")
         self.hook_limit = len(self.bounds) if (dist is None or self.world <= 1) else None
+        # second stream for the weight-gradient kernels (spconv's backward puts them there): VX_WGRAD_STREAM=0 keeps
+        # everything on the caller's stream
+        self.side = None
+        self.side_enabled = dev.type == "cuda" and os.environ.get("VX_WGRAD_STREAM", "1") != "0"
+        self.side_used = False
         for name, p in order:
             p.register_post_accumulate_grad_hook(self._make_hook(name, p))
+
+    def wgrad_stream(self, dev):
+        """The stream direct gradient writes may run on (None: the caller's). Everything that reads the flat buffer --
+        a bucket's all-reduce, finish(), and through it the optimizer -- first waits for it."""
+        if not self.side_enabled or dev != self.flat.device:
+            return None
+        if self.side is None:
+            self.side = torch.cuda.Stream(dev)
+        self.side_used = True
+        return self.side
+
+    def _join_side(self):
+        if self.side_used:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
 
     def reprobe(self):
         """Forget which buckets may fire from hooks: the next step sends everything from finish() and agrees anew."""
@@ -184,6 +204,7 @@ class GradBuckets:
         self.log.append((b, why))
         if self.dist is not None:
             lo, hi = self.bounds[b]
+            self._join_side()
             w = _all_reduce_sum(self.flat[lo:hi], self.dist, async_op=True)
             if w is not None:
                 self.works.append(w)
@@ -195,11 +216,13 @@ class GradBuckets:
         self.seen = set()
         self.fired = [False] * len(self.bounds)
         self.works, self.log, self.next, self.direct = [], [], 0, 0
+        self.side_used = False
         for p in self.params.values():
             p._vx_grad_sink.uses = 0
 
     def finish(self):
         """After backward: reduce the buckets that did not fire, wait for all of them, average."""
+        self._join_side()
         if self.hook_limit is None:
             # first step under a process group: how many leading buckets did EVERY rank complete? (one tiny MIN
             # all-reduce, issued here by every rank -- after backward, hence after every SyncBatchNorm exchange)
