@@ -324,7 +324,8 @@ def bench_train(a, dev, rank, world, dist):
                                   "fused libvx BatchNorm+add+ReLU kernels")
                                + (", one flat gradient all-reduce after backward" if buckets is None else
                                   f", gradients in one flat buffer exchanged as {len(buckets.bounds)} buckets (deep stages "
-                                  "first) overlapped with backward"),
+                                  "first) overlapped with backward"
+                                  + (", weight-gradient kernels on a second stream" if buckets.side_enabled else "")),
                    "frames_per_gpu": a.batch, "parallelism": f"dp{world}", "grad_bucket_bytes": 4 * nparam},
         "final_loss": float(loss.item()),
     }
