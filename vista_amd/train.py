@@ -64,6 +64,50 @@ def allreduce_grads_flat(params, dist=None, world=1):
     return flat.numel() * flat.element_size()
 
 
+def _concurrent_stream(dev, tries=6):
+    """A stream whose kernels really run beside the current stream's. HIP spreads its streams over a few hardware
+    queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share a queue take turns: in a process that has
+    created other streams before (captured plans, RCCL) a fresh stream lands on the current stream's queue about one
+    time in four (measured: the training step then runs at the single-stream time). So candidates from torch's pool
+    are probed with two ~0.5 ms spin kernels, one per stream; the first pair that takes about one kernel's time,
+    not two, wins. Falls back to a plain new stream if the probe cannot run."""
+    cand = torch.cuda.Stream(dev)
+    try:
+        main = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def spin(cycles, other=None):
+            torch.cuda.synchronize(dev)
+            if other is not None:
+                other.wait_stream(main)
+            e0.record(main)
+            if other is not None:
+                with torch.cuda.stream(other):
+                    torch.cuda._sleep(cycles)
+            torch.cuda._sleep(cycles)
+            if other is not None:
+                main.wait_stream(other)
+            e1.record(main)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1)
+
+        cycles = 100_000
+        spin(cycles)
+        one = spin(cycles)
+        if one <= 0:
+            return cand
+        cycles = int(min(max(cycles * 0.5 / one, 10_000), 50_000_000))      # about half a millisecond
+        one = min(spin(cycles), spin(cycles))
+        for _ in range(tries):
+            both = min(spin(cycles, cand), spin(cycles, cand))
+            if both < 1.5 * one:
+                return cand
+            cand = torch.cuda.Stream(dev)                                     # next stream of the pool, another queue
+    except Exception:
+        pass
+    return cand
+
+
 class _GradSink:
     """A parameter's slice of the flat gradient buffer, for backward functions that write a gradient in place instead
     of returning it (spconv's wgrad, the fused BatchNorm's parameter gradients): `view` is the destination, done()
@@ -158,7 +202,7 @@ class GradBuckets:
         if not self.side_enabled or dev != self.flat.device:
             return None
         if self.side is None:
-            self.side = torch.cuda.Stream(dev)
+            self.side = _concurrent_stream(dev)
         self.side_used = True
         return self.side
 
