@@ -60,6 +60,9 @@ def parse(argv=None):
                     help="inference: per-layer launches from the host (no captured plan), the round-1 path (A/B)")
     ap.add_argument("--dispatch", default=None, choices=["queued", "graph"],
                     help="how a sync-free step is issued: launches queued on the stream, or one captured HIP graph")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="two plans in flight (vista_amd.engine.FramePipeline2): the voxelizer + rulebooks of step k + 1 "
+                         "run beside the convolutions of step k; a step's output is collected two submits later")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     a = ap.parse_args(argv)
@@ -156,14 +159,17 @@ def timed_infer(step, steps, warmup, barrier, record=False):
     that: `value` comes from a pass that records nothing)."""
     import torch
     from vista_amd import ops
+    finish = getattr(step, "finish", lambda: None)   # a pipelined step: wait for (and check) what is still in flight
     for _ in range(warmup):
         step()
+    finish()
     barrier()
     torch.cuda.synchronize()
     ops.TIMING = [] if record else None
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
+    finish()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -362,10 +368,18 @@ def build_infer(a, dev, rank, dtype_name=None, geometry=None, batch=None):
     return gen, grid, engine, frames
 
 
-def make_step(a, gen, grid, engine, frames, tail=None):
+def make_step(a, gen, grid, engine, frames, tail=None, pipeline=None):
     import torch
-    from vista_amd.engine import FramePipeline
+    from vista_amd.engine import FramePipeline, FramePipeline2
     pipe = FramePipeline(gen, engine, groups=a.streams) if a.streams > 1 else None
+    pipeline = a.pipeline if pipeline is None else pipeline
+    if pipeline and not engine.eager and tail is None and pipe is None:
+        pipe2 = FramePipeline2(engine, gen, grid)
+
+        def step2():
+            return pipe2.submit(frames)
+        step2.finish = pipe2.drain        # timed_infer collects the steps in flight before it stops the clock
+        return step2
 
     def step():
         if pipe is not None:
@@ -419,7 +433,9 @@ def run_infer(a, dev, rank, world, dist, backend, barrier):
                                f"inputs resident in HBM (BASELINE.json {cfg_name})",
                    "frames_per_gpu": a.batch, "points_per_frame": int(np.mean([f.shape[0] for f in frames])),
                    "parallelism": f"frame-sharded x{world}",
-                   "dispatch": "eager per-layer launches" if a.eager else engine.dispatch_name()},
+                   "dispatch": "eager per-layer launches" if a.eager else engine.dispatch_name()
+                   + (", two plans in flight: geometry graph of step k + 1 beside the feature graph of step k"
+                      if a.pipeline and not a.full_net and a.streams == 1 else "")},
         "backend": backend, "world_size_seen": dist.get_world_size() if dist is not None else 1,
     }
     if rank == 0:
@@ -442,7 +458,7 @@ def f32_arithmetic_name():
 
 
 def infer_variant(a, dev, rank, dtype_name, geometry, batch, steps, want_roofline=False, want_phases=False,
-                  f32_products=None):
+                  f32_products=None, pipeline=False):
     """One more configuration of BASELINE.json through the same code, for the `variants` object."""
     if f32_products is not None:
         from vista_amd import ops
@@ -454,8 +470,8 @@ def infer_variant(a, dev, rank, dtype_name, geometry, batch, steps, want_rooflin
             ops.set_f32_products(old)
         return out
     gen, grid, engine, frames = build_infer(a, dev, rank, dtype_name, geometry, batch)
-    step = make_step(a, gen, grid, engine, frames)
-    dt, _, _ = timed_infer(step, steps, 2, lambda: None)
+    step = make_step(a, gen, grid, engine, frames, pipeline=pipeline)
+    dt, _, _ = timed_infer(step, steps, 2 if not pipeline else 4, lambda: None)
     out = {"frames_per_s": batch * steps / dt, "ms_per_step": 1e3 * dt / steps}
     if want_roofline or want_phases:
         ev_step = make_step(a, gen, grid, engine.eager_twin(), frames)
@@ -505,6 +521,9 @@ def main():
                                                      f32_products=0)
                 v["f32_split9_batch8"] = infer_variant(a, dev, rank, "fp32", "FHD", a.batch, a.steps,
                                                        want_roofline=True, f32_products=9)
+                # throughput mode, two plans in flight (geometry of step k + 1 beside the convolutions of step k)
+                v["pipelined_batch8"] = infer_variant(a, dev, rank, "fp32", "FHD", a.batch, a.steps, pipeline=True)
+                v["pipelined_batch1"] = infer_variant(a, dev, rank, "fp32", "FHD", 1, st, pipeline=True)
                 v["bf16_batch8"] = infer_variant(a, dev, rank, "bf16", "FHD", a.batch, a.steps, want_roofline=True)
                 v["bf16_batch1"] = infer_variant(a, dev, rank, "bf16", "FHD", 1, st)
                 v["stress_batch1"] = infer_variant(a, dev, rank, "fp32", "STRESS", 1, 5, want_phases=True)

@@ -272,6 +272,79 @@ def test_plan_error_word_is_not_sticky(dev):
     assert next(iter(eng._plans.values())) is plan
 
 
+@pytest.mark.parametrize("kind,geometry", [("SpMiddleResNetFHD", "FHD"), ("MultiViewBackbone", "VISTA")])
+def test_two_plans_in_flight_equal_forward_frames_bitwise(kind, geometry, dev):
+    """FramePipeline2 (geometry graph of step k + 1 beside the feature graph of step k, two alternating slots): every
+    output, in submission order, is bit for bit forward_frames' -- full-size frames, repeated and changing frame sets,
+    and a change of the batch size in mid-stream (slots re-planned)."""
+    from vista_amd.engine import FramePipeline2
+    from vista_amd.synth import GEOMETRIES, grid_size
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES[geometry]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    eng = _engine(kind, dev, dispatch="graph")
+    sets = [_frames(dev, seeds, 10) for seeds in ([0, 1], [7, 5], [3, 9], [4])]
+
+    def tup(o):
+        return tuple(t.clone() for t in o) if isinstance(o, tuple) else (o.clone(),)
+    ref = [tup(eng.forward_frames(gen, fr, grid)) for fr in sets]
+    pipe = FramePipeline2(eng, gen, grid)
+    order = [0, 1, 2, 0, 0, 3, 3, 1, 2]
+    outs = []
+    for j in order:
+        o = pipe.submit(sets[j])
+        if o is not None:
+            outs.append(tup(o))
+    outs += [tup(o) for o in pipe.drain()]
+    assert len(outs) == len(order) and pipe.drain() == []
+    for j, o in zip(order, outs):
+        assert len(o) == len(ref[j])
+        for a, b in zip(o, ref[j]):
+            assert torch.equal(_bits(a), _bits(b))
+    assert pipe.rebuilt == 6          # 2 slots x (batch 2, batch 1, batch 2 again)
+    pipe.close()
+    assert all(p is None for p in pipe.slots)
+
+
+def test_two_plans_in_flight_overflow_is_rerun_exactly(dev, monkeypatch):
+    """Slots whose capacities are far too small: the overflowing steps come back through forward_frames' exact re-plan
+    (same bits as the eager path), and the slots are rebuilt at least that large before their next use."""
+    from vista_amd.engine import FramePipeline2, FusedBackbone
+    from vista_amd.synth import GEOMETRIES, grid_size
+    from vista_amd.voxel import VoxelGenerator
+    rg, vs, T, mv = GEOMETRIES["SMALL"]
+    gen = VoxelGenerator(vs, rg, T, mv)
+    grid = grid_size(rg, vs).tolist()
+    eng = _engine("SpMiddleResNetFHD", dev, dispatch="graph")
+    real = FusedBackbone._probe
+    builds = []
+
+    def stingy(self, gen, frames, grid):
+        rows, need = real(self, gen, frames, grid)
+        builds.append(1)
+        if len(builds) <= 2:             # the two slots' first plans
+            return max(1, rows // 3), [max(1, n // 3) for n in need]
+        return rows, need
+    monkeypatch.setattr(FusedBackbone, "_probe", stingy)
+    monkeypatch.setattr(FusedBackbone, "_cap", staticmethod(lambda n, h: max(64, int(n))))
+    sets = [_frames(dev, [11, 12], 3), _frames(dev, [13, 14], 3)]
+    pipe = FramePipeline2(eng, gen, grid)
+    order = [0, 1, 0, 1, 1]
+    outs = []
+    for j in order:
+        o = pipe.submit(sets[j])
+        if o is not None:
+            outs.append(o.clone())
+    outs += [o.clone() for o in pipe.drain()]
+    eager = eng.eager_twin()
+    assert len(outs) == len(order)
+    for j, o in zip(order, outs):
+        assert torch.equal(_bits(o), _bits(eager.forward_frames(gen, sets[j], grid)))
+    assert pipe.floor is not None and all(p.cap_rows >= pipe.floor.cap_rows for p in pipe.slots)
+    pipe.close()
+
+
 def test_plan_soak_random_frame_sets(dev):
     """Forty random frame sets (1-3 frames of 1-4 sweeps, empty-ish to large) through ONE graph engine and one queued
     engine: every result bitwise the eager path's, plans re-used / re-planned / rebuilt as sizes move, nothing leaks

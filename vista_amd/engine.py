@@ -228,6 +228,8 @@ class FramePlan:
         self.offsets = torch.zeros((nf + 1,), dtype=torch.int64, device=dev)
         self.h_offsets = torch.zeros((nf + 1,), dtype=torch.int64).pin_memory()
         self.graph = None
+        self.graph_geo = self.graph_feat = None    # capture_pair(): geometry and feature pass as two graphs
+        self._geo = None
         self.out = None
         self.closed = False
         self.limit = None          # diagnostic (tools/graph_probe.py): stop after this many steps of the middle stack
@@ -301,6 +303,50 @@ class FramePlan:
         rv = rv.permute(0, 1, 4, 3, 2).contiguous().view(n, c * w, h, d)
         return bev, rv
 
+    def _geometry(self):
+        """Everything of a step that depends on the points alone, on the current stream: error word, voxelizer + mean
+        VFE, every rulebook. -> (state, args) for _features, which then finds all its rulebooks in the cache."""
+        from . import ops_dn
+        e, g = self.engine, self.gen
+        ops.fill_(self.counts[0:1], 0)
+        mean, coords, _ = ops_dn.voxelize_batch_dn(self.points, self.offsets, self.n_frames, g.voxel_size,
+                                                   g.point_cloud_range, g.max_num_points_per_voxel, self.cap_rows,
+                                                   self.counts[1:2 + self.n_frames])
+        sparse_shape = [int(v) for v in (np.array(self.grid[::-1]) + [1, 0, 0])]
+        cache = {"next_conv": 0, ("n", id(coords)): self.counts[1:2]}
+        st = _State(mean, coords, sparse_shape, self.n_frames, cache)
+        args = (self.caps, self.counts, self.slot, self.counts[0:1])
+        mid = _run_dn(e.middle, st, *args, geom_only=True)
+        if e.kind != "SpMiddleResNetFHD":
+            _run_dn(e.bev, mid, *args, geom_only=True)
+            _run_dn(e.rv, mid, *args, geom_only=True)
+        return st, args
+
+    def capture_pair(self):
+        """The step as TWO graphs sharing one memory pool: `graph_geo` (voxelizer + rulebooks) and `graph_feat` (the
+        convolutions + dense()), for FramePipeline2, which runs the geometry of the next step beside the convolutions
+        of this one. Same kernels on the same operands as capture()'s single graph: the outputs are the same bits."""
+        from . import ops_dn as od
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            st, args = self._geometry()
+            self._features(st, args, od)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        del side, st, args
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with _capture_guard():
+            ops.L.trace("capture (geometry) begin")
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"), torch.no_grad():
+                self._geo = self._geometry()
+            ops.L.trace("capture (features) begin")
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"), torch.no_grad():
+                self.out = self._features(*self._geo, od)
+            ops.L.trace("capture end")
+        self.graph_geo, self.graph_feat = g1, g2
+        return self
+
     def capture(self):
         """One un-captured pass (loads kernels, sets function attributes, fills the allocator), then the capture."""
         side = torch.cuda.Stream(self.dev)
@@ -326,11 +372,14 @@ class FramePlan:
             if self not in _deferred_close:
                 _deferred_close.append(self)
             return
-        graph, self.graph, self.out = self.graph, None, None
-        if graph is not None:
-            torch.cuda.synchronize(self.dev)       # no replay of it in flight
-            graph.reset()                          # hipGraphExecDestroy + release of its private pool
-            del graph
+        graphs = [g for g in (self.graph_feat, self.graph_geo, self.graph) if g is not None]
+        self.graph = self.graph_geo = self.graph_feat = None
+        self.out = self._geo = None
+        if graphs:
+            torch.cuda.synchronize(self.dev)       # no replay of them in flight
+            for graph in graphs:
+                graph.reset()                      # hipGraphExecDestroy + release of its private pool
+            del graphs
         self.points = self.offsets = self.counts = None
         self.closed = True
 
@@ -462,21 +511,24 @@ class FusedBackbone:
     def _products(self):
         return self.f32_products if self.f32_products is not None else int(ops.L.lib().vx_spconv_get_f32_products())
 
-    def _build_plan(self, gen, frames, grid, old=None, products=None):
+    def _build_plan(self, gen, frames, grid, old=None, products=None, pair=False, floors=()):
         """Capacities from an eager geometry pass over these clouds (exact counts, with its host syncs: paid once
-        per plan), never below those of the plan being replaced."""
+        per plan), never below those of the plan being replaced (`old`, closed here) nor of the plans in `floors`."""
         need_rows, need = self._probe(gen, frames, grid)
         h = self.HEADROOM
         points = sum(int(f.shape[0]) for f in frames)
         cap_points, cap_rows, caps = self._cap(points, h), self._cap(need_rows, h), [self._cap(n, h) for n in need]
-        if old is not None:
-            cap_points, cap_rows = max(cap_points, old.cap_points), max(cap_rows, old.cap_rows)
-            caps = [max(a, b) for a, b in zip(caps, old.caps)]
+        for src in (old, *floors):
+            if src is not None and len(src.caps) == len(caps):
+                cap_points, cap_rows = max(cap_points, src.cap_points), max(cap_rows, src.cap_rows)
+                caps = [max(a, b) for a, b in zip(caps, src.caps)]
         if old is not None:
             old.close()                # its graph and pool go before the new plan allocates and captures
         plan = FramePlan(self._compiled, gen, len(frames), grid, cap_points, cap_rows, caps, frames[0].device,
                          products=products)
         plan.stage(frames)
+        if pair:
+            return plan.capture_pair()
         return plan.capture() if self.dispatch == "graph" else plan
 
     def forward_frames(self, gen, frames, grid):
@@ -586,3 +638,126 @@ class FramePipeline:
             for s in used:
                 main.wait_stream(s)
         return out
+
+
+class FramePipeline2:
+    """Throughput mode of FusedBackbone.forward_frames: two plans in flight. Frames are independent, and the first
+    ~0.9 ms of a step -- voxelizer, hash build, the first rulebook -- is a chain of small kernels nothing else runs
+    beside; so the GEOMETRY graph of step k + 1 (voxelizer + every rulebook, LDS-light kernels that fit beside a conv
+    workgroup) is replayed on a second stream while the FEATURE graph of step k (the convolutions) runs on the first.
+    Two slots (plan = buffers + graph pair) alternate; feature graphs are serialised on one stream -- two conv kernels
+    side by side gain nothing (tools/experiments/corun_probe.py) -- and a slot's geometry waits until the feature graph
+    that last read the slot's rulebooks is done.
+
+        pipe = FramePipeline2(engine, gen, grid)
+        for clouds in stream_of_frame_lists:
+            done = pipe.submit(clouds)                # -> output of the step submitted TWO calls ago, or None
+        last = pipe.drain()                           # -> the outputs still in flight, oldest first
+
+    Outputs are the plan's tensors (overwritten when their slot is submitted again, two calls later) and bitwise those
+    of forward_frames. A step whose counts exceed its slot's capacities is re-run through forward_frames (exact
+    re-plan, the output a private copy) and the slots are rebuilt with at least those capacities before their next use."""
+
+    def __init__(self, engine, gen, grid):
+        if engine.eager or engine.dispatch != "graph":
+            raise ValueError("FramePipeline2 drives a graph-dispatch FusedBackbone")
+        self.engine, self.gen, self.grid = engine, gen, list(grid)
+        self.dev = engine.dev
+        self.slots = [None, None]          # plans (buffers + geometry / feature graph)
+        self.busy = [None, None]           # clouds of the step in flight on the slot
+        self.done_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self.geo_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self.k = 0
+        self.floor = None                  # a plan whose capacities every slot must reach (set by an overflow)
+        self.feat_stream = self.geo_stream = None
+        self.rebuilt = 0
+
+    def _covers(self, plan, frames, products):
+        f = self.floor
+        return (plan is not None and not plan.closed and plan.n_frames == len(frames) and plan.products == products
+                and sum(int(c.shape[0]) for c in frames) <= plan.cap_points
+                and (f is None or len(f.caps) != len(plan.caps)
+                     or (plan.cap_rows >= f.cap_rows and all(a >= b for a, b in zip(plan.caps, f.caps)))))
+
+    def _plan(self, s, frames):
+        e = self.engine
+        products = e._products()
+        plan = self.slots[s]
+        if not self._covers(plan, frames, products):
+            old = plan if plan is not None and not plan.closed else None
+            if old is not None and old.n_frames != len(frames):
+                old.close()
+                old = None
+            plan = self.slots[s] = e._build_plan(self.gen, frames, self.grid, old, products, pair=True,
+                                                 floors=(self.slots[1 - s], self.floor))
+            self.rebuilt += 1
+        return plan
+
+    def submit(self, frames):
+        """Queue one step; -> the output of the step that used this slot before (two submits ago), or None."""
+        if self.feat_stream is None:
+            from .train import _concurrent_stream
+            # both are the pipeline's own: the caller's stream only hands the clouds over (were the feature graphs on it,
+            # "wait for the clouds" would mean "wait for the previous step's convolutions")
+            self.feat_stream = torch.cuda.Stream(self.dev)
+            with torch.cuda.stream(self.feat_stream):
+                self.geo_stream = _concurrent_stream(self.dev)   # one that really runs beside feat_stream (hardware queues)
+        s = self.k & 1
+        out = self._collect(s)
+        plan = self._plan(s, frames)
+        fs, gs = self.feat_stream, self.geo_stream
+        gs.wait_stream(torch.cuda.current_stream(self.dev))      # the caller's clouds
+        gs.wait_event(self.done_ev[s])                           # the slot's rulebooks were last read by this graph
+        with torch.cuda.stream(gs):
+            plan.stage(frames)
+            plan.graph_geo.replay()
+            self.geo_ev[s].record(gs)
+        for f in frames:
+            f.record_stream(gs)
+        fs.wait_event(self.geo_ev[s])
+        with torch.cuda.stream(fs):
+            plan.graph_feat.replay()
+            plan.h_counts.copy_(plan.counts, non_blocking=True)
+            self.done_ev[s].record(fs)
+        self.busy[s] = frames
+        self.k += 1
+        return out
+
+    def _collect(self, s):
+        frames, plan = self.busy[s], self.slots[s]
+        if frames is None:
+            return None
+        self.busy[s] = None
+        self.done_ev[s].synchronize()
+        if plan.overflow() is None:
+            return plan.out
+        # rows were dropped: exact re-run of this step through the engine's own plan (which re-plans from this very
+        # input); its capacities become the floor of both slots
+        torch.cuda.synchronize(self.dev)
+        e = self.engine
+        out = e.forward_frames(self.gen, frames, self.grid)
+        out = tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()
+        self.floor = e._plans[(id(self.gen), len(frames), tuple(self.grid), e._products())]
+        return out
+
+    def drain(self):
+        """Wait for the steps in flight; -> their outputs, oldest first."""
+        outs = []
+        for s in ((self.k & 1), (self.k & 1) ^ 1):
+            o = self._collect(s)
+            if o is not None:
+                outs.append(o)
+        return outs
+
+    def close(self):
+        self.drain()
+        for t in (0, 1):
+            if self.slots[t] is not None:
+                self.slots[t].close()
+                self.slots[t] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
