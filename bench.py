@@ -62,7 +62,7 @@ def parse(argv=None):
                     help="how a sync-free step is issued: launches queued on the stream, or one captured HIP graph")
     ap.add_argument("--pipeline", action="store_true",
                     help="two plans in flight (vista_amd.engine.FramePipeline2): the voxelizer + rulebooks of step k + 1 "
-                         "run beside the convolutions of step k; a step's output is collected two submits later")
+                         "run beside the convolutions of step k; submit() returns the previous step's output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     a = ap.parse_args(argv)

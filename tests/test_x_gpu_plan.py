@@ -276,7 +276,8 @@ def test_plan_error_word_is_not_sticky(dev):
 def test_two_plans_in_flight_equal_forward_frames_bitwise(kind, geometry, dev):
     """FramePipeline2 (geometry graph of step k + 1 beside the feature graph of step k, two alternating slots): every
     output, in submission order, is bit for bit forward_frames' -- full-size frames, repeated and changing frame sets,
-    and a change of the batch size in mid-stream (slots re-planned)."""
+    and a change of the batch size in mid-stream (slots re-planned). An output is read AFTER the submit that returned
+    it, on the caller's stream: it must not be the slot that submit has just queued work on."""
     from vista_amd.engine import FramePipeline2
     from vista_amd.synth import GEOMETRIES, grid_size
     from vista_amd.voxel import VoxelGenerator

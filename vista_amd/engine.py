@@ -651,10 +651,10 @@ class FramePipeline2:
 
         pipe = FramePipeline2(engine, gen, grid)
         for clouds in stream_of_frame_lists:
-            done = pipe.submit(clouds)                # -> output of the step submitted TWO calls ago, or None
-        last = pipe.drain()                           # -> the outputs still in flight, oldest first
+            done = pipe.submit(clouds)                # queues this step, -> output of the PREVIOUS one (None at first)
+        last = pipe.drain()                           # -> [output of the last step]
 
-    Outputs are the plan's tensors (overwritten when their slot is submitted again, two calls later) and bitwise those
+    Outputs are the plan's tensors -- valid until the next submit(), which re-uses their slot -- and bitwise those
     of forward_frames. A step whose counts exceed its slot's capacities is re-run through forward_frames (exact
     re-plan, the output a private copy) and the slots are rebuilt with at least those capacities before their next use."""
 
@@ -694,7 +694,9 @@ class FramePipeline2:
         return plan
 
     def submit(self, frames):
-        """Queue one step; -> the output of the step that used this slot before (two submits ago), or None."""
+        """Queue one step, then wait for the PREVIOUS one: -> its output (None on the first call). The step queued here
+        is already running its geometry beside that step's convolutions while the host waits. The returned tensors
+        belong to the other slot and stay untouched until the next submit()."""
         if self.feat_stream is None:
             from .train import _concurrent_stream
             # both are the pipeline's own: the caller's stream only hands the clouds over (were the feature graphs on it,
@@ -703,7 +705,7 @@ class FramePipeline2:
             with torch.cuda.stream(self.feat_stream):
                 self.geo_stream = _concurrent_stream(self.dev)   # one that really runs beside feat_stream (hardware queues)
         s = self.k & 1
-        out = self._collect(s)
+        assert self.busy[s] is None          # collected by the previous submit
         plan = self._plan(s, frames)
         fs, gs = self.feat_stream, self.geo_stream
         gs.wait_stream(torch.cuda.current_stream(self.dev))      # the caller's clouds
@@ -721,7 +723,7 @@ class FramePipeline2:
             self.done_ev[s].record(fs)
         self.busy[s] = frames
         self.k += 1
-        return out
+        return self._collect(1 - s)
 
     def _collect(self, s):
         frames, plan = self.busy[s], self.slots[s]
@@ -741,7 +743,7 @@ class FramePipeline2:
         return out
 
     def drain(self):
-        """Wait for the steps in flight; -> their outputs, oldest first."""
+        """Wait for the step in flight; -> [its output] (or [])."""
         outs = []
         for s in ((self.k & 1), (self.k & 1) ^ 1):
             o = self._collect(s)
