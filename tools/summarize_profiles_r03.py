@@ -34,4 +34,5 @@ kstats("f32_b1", "profiles/r03_bench_b1_fp32_kernel_stats.csv", "bench.py --batc
 kstats("bf16_b8", "profiles/r03_bench_b8_bf16_kernel_stats.csv", "bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-variants",
        "25 steps of kernels as for fp32")
 kstats("train_b4", "profiles/r03_train_b4_fp32_kernel_stats.csv", "bench.py --mode train --batch 4 --steps 5 --warmup 2",
-       "7 training steps, fused BatchNorm kernels, every gradient written straight into the flat buffer (no accumulate adds)")
+       "7 training steps, fused BatchNorm kernels, every gradient written straight into the flat buffer (no accumulate adds), "
+       "weight-gradient kernels on a second stream (the spin kernels are the stream probe)")
