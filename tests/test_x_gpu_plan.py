@@ -272,8 +272,9 @@ def test_plan_error_word_is_not_sticky(dev):
     assert next(iter(eng._plans.values())) is plan
 
 
+@pytest.mark.parametrize("feat_streams", ["1", "2"])
 @pytest.mark.parametrize("kind,geometry", [("SpMiddleResNetFHD", "FHD"), ("MultiViewBackbone", "VISTA")])
-def test_two_plans_in_flight_equal_forward_frames_bitwise(kind, geometry, dev):
+def test_two_plans_in_flight_equal_forward_frames_bitwise(kind, geometry, feat_streams, dev, monkeypatch):
     """FramePipeline2 (geometry graph of step k + 1 beside the feature graph of step k, two alternating slots): every
     output, in submission order, is bit for bit forward_frames' -- full-size frames, repeated and changing frame sets,
     and a change of the batch size in mid-stream (slots re-planned). An output is read AFTER the submit that returned
@@ -281,6 +282,7 @@ def test_two_plans_in_flight_equal_forward_frames_bitwise(kind, geometry, dev):
     from vista_amd.engine import FramePipeline2
     from vista_amd.synth import GEOMETRIES, grid_size
     from vista_amd.voxel import VoxelGenerator
+    monkeypatch.setenv("VX_PIPE_FEAT_STREAMS", feat_streams)     # feature graphs of the two slots on one / two streams
     rg, vs, T, mv = GEOMETRIES[geometry]
     gen = VoxelGenerator(vs, rg, T, mv)
     grid = grid_size(rg, vs).tolist()

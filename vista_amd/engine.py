@@ -645,9 +645,9 @@ class FramePipeline2:
     ~0.9 ms of a step -- voxelizer, hash build, the first rulebook -- is a chain of small kernels nothing else runs
     beside; so the GEOMETRY graph of step k + 1 (voxelizer + every rulebook, LDS-light kernels that fit beside a conv
     workgroup) is replayed on a second stream while the FEATURE graph of step k (the convolutions) runs on the first.
-    Two slots (plan = buffers + graph pair) alternate; feature graphs are serialised on one stream -- two conv kernels
-    side by side gain nothing (tools/experiments/corun_probe.py) -- and a slot's geometry waits until the feature graph
-    that last read the slot's rulebooks is done.
+    Two slots (plan = buffers + graph pair) alternate; from batch 8 on the feature graphs are serialised on one stream
+    -- two conv kernels side by side gain nothing there (tools/experiments/corun_probe.py) -- while small batches run them
+    on two (see submit); a slot's geometry waits until the feature graph that last read the slot's rulebooks is done.
 
         pipe = FramePipeline2(engine, gen, grid)
         for clouds in stream_of_frame_lists:
@@ -657,6 +657,8 @@ class FramePipeline2:
     Outputs are the plan's tensors -- valid until the next submit(), which re-uses their slot -- and bitwise those
     of forward_frames. A step whose counts exceed its slot's capacities is re-run through forward_frames (exact
     re-plan, the output a private copy) and the slots are rebuilt with at least those capacities before their next use."""
+
+    TWO_STREAMS_UP_TO = 4      # frames per step up to which the two slots' feature graphs run side by side
 
     def __init__(self, engine, gen, grid):
         if engine.eager or engine.dispatch != "graph":
@@ -704,10 +706,17 @@ class FramePipeline2:
             self.feat_stream = torch.cuda.Stream(self.dev)
             with torch.cuda.stream(self.feat_stream):
                 self.geo_stream = _concurrent_stream(self.dev)   # one that really runs beside feat_stream (hardware queues)
+            with torch.cuda.stream(self.feat_stream):
+                self.feat_stream2 = _concurrent_stream(self.dev)
         s = self.k & 1
         assert self.busy[s] is None          # collected by the previous submit
         plan = self._plan(s, frames)
-        fs, gs = self.feat_stream, self.geo_stream
+        # Small batches leave CUs idle in every kernel's last partial round of tiles (one FHD frame: 332 tiles of the
+        # 128-channel layers on 256 CUs): there the two slots' feature graphs run on two streams and fill each other's
+        # gaps (batch 1: 225 -> 248 frames/s, bf16 487 -> 567; batch 4 +2 %). From batch 8 on the rounds are full and
+        # two conv kernels side by side gain nothing (-0.6 %): one feature stream. VX_PIPE_FEAT_STREAMS=1|2 overrides.
+        two = os.environ.get("VX_PIPE_FEAT_STREAMS") or ("2" if len(frames) <= self.TWO_STREAMS_UP_TO else "1")
+        fs, gs = (self.feat_stream2 if (s == 1 and two == "2") else self.feat_stream), self.geo_stream
         gs.wait_stream(torch.cuda.current_stream(self.dev))      # the caller's clouds
         gs.wait_event(self.done_ev[s])                           # the slot's rulebooks were last read by this graph
         with torch.cuda.stream(gs):
