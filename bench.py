@@ -31,6 +31,7 @@ sys.path.insert(0, REPO)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix = vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense matrix peak (the chip holds a lower clock under bf16 load)
 PEAK_HBM_GBS = 8000.0
+EV_STEPS = 20                  # steps of the separate instrumented pass (roofline / phases), whatever --steps says
 
 
 def parse(argv=None):
@@ -443,9 +444,12 @@ def run_infer(a, dev, rank, world, dist, backend, barrier):
         # NOT the pass `value` comes from
         ev_engine = engine.eager_twin()
         ev_step = make_step(a, gen, grid, ev_engine, frames, tail)
-        _, timing, _ = timed_infer(ev_step, a.steps, 1, lambda: None, record=True)
+        # at most EV_STEPS steps: every record keeps its rulebook alive (pair counts are read afterwards, off the clock),
+        # about 1 GB per batch-8 step
+        ev_steps = min(a.steps, EV_STEPS)
+        _, timing, _ = timed_infer(ev_step, ev_steps, 1, lambda: None, record=True)
         res["roofline"] = dominant_kernel_roofline(timing, a.dtype)
-        res["phases"] = phase_report(timing, a.steps, a.batch, a.geometry)
+        res["phases"] = phase_report(timing, ev_steps, a.batch, a.geometry)
     return res, (gen, grid, engine, frames, tail)
 
 
@@ -475,11 +479,12 @@ def infer_variant(a, dev, rank, dtype_name, geometry, batch, steps, want_rooflin
     out = {"frames_per_s": batch * steps / dt, "ms_per_step": 1e3 * dt / steps}
     if want_roofline or want_phases:
         ev_step = make_step(a, gen, grid, engine.eager_twin(), frames)
-        _, timing, _ = timed_infer(ev_step, steps, 1, lambda: None, record=True)
+        ev_steps = min(steps, EV_STEPS)
+        _, timing, _ = timed_infer(ev_step, ev_steps, 1, lambda: None, record=True)
         if want_roofline:
             out["roofline"] = dominant_kernel_roofline(timing, dtype_name)
         if want_phases:
-            out["phases"] = phase_report(timing, steps, batch, geometry)
+            out["phases"] = phase_report(timing, ev_steps, batch, geometry)
     return out
 
 
